@@ -1,0 +1,623 @@
+/*
+ * pt_oracle.c -- CPU oracle (TEST INFRASTRUCTURE ONLY, see pt_oracle.h).
+ *
+ * Citations "ref:" are relative to /root/reference/.  "spec:" marks parts the
+ * reference ships as TODO stubs; their semantics are defined in DESIGN.md
+ * ("Canonical semantics") and this file is the normative statement.
+ *
+ * Build: gcc -O2 -std=c99 -ffp-contract=off -fno-fast-math (see Makefile).
+ */
+#include "pt_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define O_PI 3.1415926535897932384626422832795028841971            /* ref: src/utilities.h:20 (double) */
+#define O_TWO_PI 6.2831853071795864769252867665590057683943        /* ref: src/utilities.h:21 (double) */
+#define O_SQRT_OF_ONE_THIRD 0.5773502691896257645091487805019574556476 /* ref: src/utilities.h:22 (double) */
+#define O_EPSILON .000000001                                        /* ref: src/utilities.h:24 (double) */
+#define O_RAY_BIAS_AMOUNT 0.0002f                                   /* ref: src/utilities.h:26, used as fp32 */
+
+/* ------------------------------------------------------------------ */
+/* GLM 0.9.5.4 vector arithmetic, restated (fp32, operation order kept) */
+/* ------------------------------------------------------------------ */
+static o_vec3 v3(float x, float y, float z) { o_vec3 r; r.x = x; r.y = y; r.z = z; return r; }
+static o_vec4 v4(o_vec3 v, float w) { o_vec4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = w; return r; }
+static o_vec3 add3(o_vec3 a, o_vec3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static o_vec3 sub3(o_vec3 a, o_vec3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static o_vec3 mul3(o_vec3 a, o_vec3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static o_vec3 scale3(float s, o_vec3 v) { return v3(s * v.x, s * v.y, s * v.z); } /* float*vec3 == vec3*float */
+static o_vec3 neg3(o_vec3 a) { return v3(-a.x, -a.y, -a.z); }
+/* ref: external/include/glm/detail/func_geometric.inl:66-73  tmp = x*y; tmp.x + tmp.y + tmp.z */
+static float dot3(o_vec3 a, o_vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+/* ref: func_geometric.inl:215-227 */
+static o_vec3 cross3(o_vec3 x, o_vec3 y)
+{
+    return v3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
+}
+/* ref: func_geometric.inl:108-115  sqrt(x*x + y*y + z*z) */
+static float length3(o_vec3 v) { float sqr = v.x * v.x + v.y * v.y + v.z * v.z; return sqrtf(sqr); }
+/* ref: func_geometric.inl:256-265 + func_exponential.inl:226-229  x * (1.0f / sqrt(sqr)) */
+static o_vec3 normalize3(o_vec3 v)
+{
+    float sqr = v.x * v.x + v.y * v.y + v.z * v.z;
+    float inv = 1.0f / sqrtf(sqr);
+    return v3(v.x * inv, v.y * inv, v.z * inv);
+}
+
+/* ------------------------------------------------------------------ */
+/* RNG                                                                 */
+/* ------------------------------------------------------------------ */
+/* ref: src/intersections.h:26-34 */
+unsigned o_hash(unsigned a)
+{
+    a = (a + 0x7ed55d16u) + (a << 12);
+    a = (a ^ 0xc761c23cu) ^ (a >> 19);
+    a = (a + 0x165667b1u) + (a << 5);
+    a = (a + 0xd3a2646cu) ^ (a << 9);
+    a = (a + 0xfd7046c5u) + (a << 3);
+    a = (a ^ 0xb55a4f09u) ^ (a >> 16);
+    return a;
+}
+
+/* thrust::default_random_engine == minstd_rand == LCG(a=48271, c=0, m=2^31-1), third-party (CUDA toolkit
+ * thrust, not vendored; call sites ref: src/raytraceKernel.cu:32-35, src/intersections.h:135-137).
+ * Restated from rocThrust 2.8.5 thrust/random/detail/linear_congruential_engine.inl (seed) and
+ * thrust/random/detail/mod.h (Schrage's method). */
+#define O_MINSTD_A 48271u
+#define O_MINSTD_M 2147483647u
+void o_minstd_seed(unsigned *state, unsigned s)
+{
+    unsigned x = s % O_MINSTD_M;
+    if (x == 0u) x = 1u % O_MINSTD_M;
+    *state = x;
+}
+unsigned o_minstd_next(unsigned *state)
+{
+    const unsigned q = O_MINSTD_M / O_MINSTD_A, r = O_MINSTD_M % O_MINSTD_A;
+    unsigned x = *state;
+    unsigned t1 = O_MINSTD_A * (x % q);
+    unsigned t2 = r * (x / q);
+    if (t1 >= t2) x = t1 - t2; else x = O_MINSTD_M - t2 + t1;
+    *state = x;
+    return x;
+}
+/* thrust::uniform_real_distribution<float>(a,b), thrust/random/detail/uniform_real_distribution.inl:
+ * result = float(urng() - min); result /= (1.0f + float(max - min)); return result*(b-a) + a */
+float o_uniform_real(unsigned *state, float a, float b)
+{
+    float result = (float)(o_minstd_next(state) - 1u);
+    result /= (1.0f + (float)(2147483646u - 1u));
+    return (result * (b - a)) + a;
+}
+float o_u01(unsigned *state) { return o_uniform_real(state, 0.0f, 1.0f); }
+
+/* spec: one minstd stream per (global pixel, iteration, key); key 0 = camera jitter,
+ * key b+1 = bounce b.  Integer-only, so identical on every device and independent of ray slot. */
+unsigned o_stream_seed(unsigned pixel, unsigned iteration, unsigned key, unsigned seed)
+{
+    return o_hash(pixel ^ o_hash(iteration ^ o_hash(key + seed * 2654435769u)));
+}
+
+/* ------------------------------------------------------------------ */
+/* intersections.h                                                     */
+/* ------------------------------------------------------------------ */
+/* ref: src/intersections.h:37-43 (EPSILON is a double literal: the compare is done in double) */
+int o_epsilonCheck(float a, float b)
+{
+    return ((double)fabsf(fabsf(a) - fabsf(b)) < O_EPSILON) ? 1 : 0;
+}
+
+/* ref: src/intersections.h:46-48 */
+o_vec3 o_getPointOnRay(o_ray r, float t)
+{
+    return add3(r.origin, scale3((float)(t - .0001f), normalize3(r.direction)));
+}
+
+/* ref: src/intersections.h:53-59 (row w of the matrix is never read) */
+o_vec3 o_multiplyMV(o_mat4 m, o_vec4 v)
+{
+    o_vec3 r;
+    r.x = (m.x.x * v.x) + (m.x.y * v.y) + (m.x.z * v.z) + (m.x.w * v.w);
+    r.y = (m.y.x * v.x) + (m.y.y * v.y) + (m.y.z * v.z) + (m.y.w * v.w);
+    r.z = (m.z.x * v.x) + (m.z.y * v.y) + (m.z.z * v.z) + (m.z.w * v.w);
+    return r;
+}
+
+/* ref: src/intersections.h:62-64 (1.0 is a double literal: divide in double, store as fp32) */
+o_vec3 o_getInverseDirectionOfRay(o_ray r)
+{
+    return v3((float)(1.0 / (double)r.direction.x), (float)(1.0 / (double)r.direction.y),
+              (float)(1.0 / (double)r.direction.z));
+}
+
+/* ref: src/intersections.h:67-70 */
+o_vec3 o_getSignOfRay(o_ray r)
+{
+    o_vec3 inv = o_getInverseDirectionOfRay(r);
+    return v3((float)(int)(inv.x < 0), (float)(int)(inv.y < 0), (float)(int)(inv.z < 0));
+}
+
+/* ref: src/intersections.h:81-117 */
+float o_sphereIntersectionTest(const o_staticGeom *sphere, o_ray r, o_vec3 *intersectionPoint, o_vec3 *normal)
+{
+    float radius = .5f;
+
+    o_vec3 ro = o_multiplyMV(sphere->inverseTransform, v4(r.origin, 1.0f));
+    o_vec3 rd = normalize3(o_multiplyMV(sphere->inverseTransform, v4(r.direction, 0.0f)));
+
+    o_ray rt; rt.origin = ro; rt.direction = rd;
+
+    float vDotDirection = dot3(rt.origin, rt.direction);
+    /* pow(radius, 2) is std::pow(float,int) -> double (C++11), so the bracket and the outer subtraction
+     * are evaluated in double and rounded once on assignment (ref line 90). */
+    float radicand = (float)((double)(vDotDirection * vDotDirection) -
+                             ((double)dot3(rt.origin, rt.origin) - pow((double)radius, 2.0)));
+    if (radicand < 0) return -1;
+
+    float squareRoot = sqrtf(radicand);
+    float firstTerm = -vDotDirection;
+    float t1 = firstTerm + squareRoot;
+    float t2 = firstTerm - squareRoot;
+
+    float t = 0;
+    if (t1 < 0 && t2 < 0) {
+        return -1;
+    } else if (t1 > 0 && t2 > 0) {
+        t = (t2 < t1) ? t2 : t1;          /* std::min(t1, t2) */
+    } else {
+        t = (t1 < t2) ? t2 : t1;          /* std::max(t1, t2) */
+    }
+
+    o_vec3 realIntersectionPoint = o_multiplyMV(sphere->transform, v4(o_getPointOnRay(rt, t), 1.0f));
+    o_vec3 realOrigin = o_multiplyMV(sphere->transform, v4(v3(0, 0, 0), 1.0f));
+
+    *intersectionPoint = realIntersectionPoint;
+    *normal = normalize3(sub3(realIntersectionPoint, realOrigin));
+
+    return length3(sub3(r.origin, realIntersectionPoint));
+}
+
+/* spec (ref stub: src/intersections.h:72-77; "should work in the same way as sphereIntersectionTest",
+ * README.md:121-123): unit cube [-.5,.5]^3 in object space, slab test.  min/max are written as explicit
+ * compares so that inf/NaN slabs behave identically on every target. */
+float o_boxIntersectionTest(const o_staticGeom *box, o_ray r, o_vec3 *intersectionPoint, o_vec3 *normal)
+{
+    o_vec3 ro = o_multiplyMV(box->inverseTransform, v4(r.origin, 1.0f));
+    o_vec3 rd = normalize3(o_multiplyMV(box->inverseTransform, v4(r.direction, 0.0f)));
+    o_ray rt; rt.origin = ro; rt.direction = rd;
+
+    const float o[3] = { ro.x, ro.y, ro.z };
+    const float d[3] = { rd.x, rd.y, rd.z };
+    float tmin = 0, tmax = 0;
+    int amin = 0, amax = 0;
+    for (int a = 0; a < 3; a++) {
+        float inv = 1.0f / d[a];
+        float t0 = (-0.5f - o[a]) * inv;
+        float t1 = (0.5f - o[a]) * inv;
+        float tn = (t0 < t1) ? t0 : t1;
+        float tf = (t0 < t1) ? t1 : t0;
+        if (a == 0 || tn > tmin) { tmin = tn; amin = a; }
+        if (a == 0 || tf < tmax) { tmax = tf; amax = a; }
+    }
+    if (tmax < tmin || tmax < 0) return -1;
+
+    float t; int axis; float sgn;
+    if (tmin > 0) { t = tmin; axis = amin; sgn = (d[axis] > 0) ? -1.0f : 1.0f; }   /* entry face */
+    else          { t = tmax; axis = amax; sgn = (d[axis] > 0) ? 1.0f : -1.0f; }   /* exit face (origin inside) */
+
+    o_vec3 n_obj = v3(axis == 0 ? sgn : 0.0f, axis == 1 ? sgn : 0.0f, axis == 2 ? sgn : 0.0f);
+
+    o_vec3 realIntersectionPoint = o_multiplyMV(box->transform, v4(o_getPointOnRay(rt, t), 1.0f));
+    *intersectionPoint = realIntersectionPoint;
+    *normal = normalize3(o_multiplyMV(box->transform, v4(n_obj, 0.0f)));
+    return length3(sub3(r.origin, realIntersectionPoint));
+}
+
+/* ref: src/intersections.h:120-129; glm::distance(p0,p1) = length(p1 - p0) */
+o_vec3 o_getRadiuses(const o_staticGeom *geom)
+{
+    o_vec3 origin = o_multiplyMV(geom->transform, v4(v3(0, 0, 0), 1.0f));
+    o_vec3 xmax = o_multiplyMV(geom->transform, v4(v3(.5f, 0, 0), 1.0f));
+    o_vec3 ymax = o_multiplyMV(geom->transform, v4(v3(0, .5f, 0), 1.0f));
+    o_vec3 zmax = o_multiplyMV(geom->transform, v4(v3(0, 0, .5f), 1.0f));
+    return v3(length3(sub3(xmax, origin)), length3(sub3(ymax, origin)), length3(sub3(zmax, origin)));
+}
+
+/* ref: src/intersections.h:133-175 */
+o_vec3 o_getRandomPointOnCube(const o_staticGeom *cube, float randomSeed)
+{
+    unsigned rng; o_minstd_seed(&rng, o_hash((unsigned)randomSeed));
+
+    o_vec3 radii = o_getRadiuses(cube);
+    float side1 = radii.x * radii.y * 4.0f;
+    float side2 = radii.z * radii.y * 4.0f;
+    float side3 = radii.x * radii.z * 4.0f;
+    float totalarea = 2.0f * (side1 + side2 + side3);
+
+    float russianRoulette = o_uniform_real(&rng, 0, 1);
+
+    o_vec3 point;
+    if (russianRoulette < (side1 / totalarea)) {
+        float a = o_uniform_real(&rng, -0.5f, 0.5f), b = o_uniform_real(&rng, -0.5f, 0.5f);
+        point = v3(a, b, .5f);
+    } else if (russianRoulette < ((side1 * 2) / totalarea)) {
+        float a = o_uniform_real(&rng, -0.5f, 0.5f), b = o_uniform_real(&rng, -0.5f, 0.5f);
+        point = v3(a, b, -.5f);
+    } else if (russianRoulette < (((side1 * 2) + (side2)) / totalarea)) {
+        float a = o_uniform_real(&rng, -0.5f, 0.5f), b = o_uniform_real(&rng, -0.5f, 0.5f);
+        point = v3(.5f, a, b);
+    } else if (russianRoulette < (((side1 * 2) + (side2 * 2)) / totalarea)) {
+        float a = o_uniform_real(&rng, -0.5f, 0.5f), b = o_uniform_real(&rng, -0.5f, 0.5f);
+        point = v3(-.5f, a, b);
+    } else if (russianRoulette < (((side1 * 2) + (side2 * 2) + (side3)) / totalarea)) {
+        float a = o_uniform_real(&rng, -0.5f, 0.5f), b = o_uniform_real(&rng, -0.5f, 0.5f);
+        point = v3(a, .5f, b);
+    } else {
+        float a = o_uniform_real(&rng, -0.5f, 0.5f), b = o_uniform_real(&rng, -0.5f, 0.5f);
+        point = v3(a, -.5f, b);
+    }
+    return o_multiplyMV(cube->transform, v4(point, 1.0f));
+}
+
+/* spec (ref stub: src/intersections.h:177-182): uniform point on the object-space sphere r=.5 */
+o_vec3 o_getRandomPointOnSphere(const o_staticGeom *sphere, float randomSeed)
+{
+    unsigned rng; o_minstd_seed(&rng, o_hash((unsigned)randomSeed));
+    float xi1 = o_uniform_real(&rng, 0, 1), xi2 = o_uniform_real(&rng, 0, 1);
+    o_vec3 d = o_getRandomDirectionInSphere(xi1, xi2, O_TRIG_POLY);
+    return o_multiplyMV(sphere->transform, v4(scale3(0.5f, d), 1.0f));
+}
+
+/* ------------------------------------------------------------------ */
+/* interactions.h                                                      */
+/* ------------------------------------------------------------------ */
+/* spec: deterministic sincos for a in [0, 2*pi] built from fp32 + - * only (3-term Cody-Waite reduction
+ * by pi/2, cephes minimax polynomials), so the HIP kernels and this oracle agree bit for bit.  glibc and
+ * ROCm OCML sinf/cosf differ in the last place, which a path tracer amplifies into different hit/miss
+ * decisions; max abs error of this routine vs libm on [0,2pi] is < 2.4e-7 (tests/test_oracle_kat.py). */
+void o_sincos_poly(float a, float *s_out, float *c_out)
+{
+    int k = (int)(a * 0.636619772f + 0.5f);
+    float fk = (float)k;
+    float r = ((a - fk * 1.5703125f) - fk * 4.837512969970703125e-4f) - fk * 7.54978995489188216e-8f;
+    float z = r * r;
+    float s = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    float c = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z
+              - 0.5f * z + 1.0f;
+    switch (k & 3) {
+    case 0: *s_out = s;  *c_out = c;  break;
+    case 1: *s_out = c;  *c_out = -s; break;
+    case 2: *s_out = -s; *c_out = -c; break;
+    default: *s_out = -c; *c_out = s; break;
+    }
+}
+
+/* ref: src/interactions.h:62-87 */
+o_vec3 o_calculateRandomDirectionInHemisphere(o_vec3 normal, float xi1, float xi2, int trig_mode)
+{
+    float up = sqrtf(xi1);
+    float over = sqrtf(1 - up * up);
+    float around = (float)((double)xi2 * O_TWO_PI);          /* TWO_PI is a double literal */
+
+    o_vec3 directionNotNormal;
+    if ((double)fabsf(normal.x) < O_SQRT_OF_ONE_THIRD) {      /* compared in double */
+        directionNotNormal = v3(1, 0, 0);
+    } else if ((double)fabsf(normal.y) < O_SQRT_OF_ONE_THIRD) {
+        directionNotNormal = v3(0, 1, 0);
+    } else {
+        directionNotNormal = v3(0, 0, 1);
+    }
+
+    o_vec3 perpendicularDirection1 = normalize3(cross3(normal, directionNotNormal));
+    o_vec3 perpendicularDirection2 = normalize3(cross3(normal, perpendicularDirection1));
+
+    float sn, cs;
+    if (trig_mode == O_TRIG_LIBM) { cs = cosf(around); sn = sinf(around); }
+    else o_sincos_poly(around, &sn, &cs);
+
+    return add3(add3(scale3(up, normal), scale3(cs * over, perpendicularDirection1)),
+                scale3(sn * over, perpendicularDirection2));
+}
+
+/* spec (ref stub: src/interactions.h:89-95): uniform direction on the unit sphere */
+o_vec3 o_getRandomDirectionInSphere(float xi1, float xi2, int trig_mode)
+{
+    float z = 1.0f - 2.0f * xi1;
+    float rr = 1.0f - z * z;
+    float rad = sqrtf(rr < 0.0f ? 0.0f : rr);
+    float around = (float)((double)xi2 * O_TWO_PI);
+    float sn, cs;
+    if (trig_mode == O_TRIG_LIBM) { cs = cosf(around); sn = sinf(around); }
+    else o_sincos_poly(around, &sn, &cs);
+    return v3(rad * cs, rad * sn, z);
+}
+
+/* spec (ref stub: src/interactions.h:47-50): mirror law d - 2(d.n)n */
+o_vec3 o_calculateReflectionDirection(o_vec3 normal, o_vec3 incident)
+{
+    float k = 2.0f * dot3(incident, normal);
+    return sub3(incident, scale3(k, normal));
+}
+
+/* spec (ref stub: src/interactions.h:42-44): Snell refraction; `normal` faces the incident side
+ * (dot(normal, incident) <= 0), `incident` is unit length.  Total internal reflection -> (0,0,0). */
+o_vec3 o_calculateTransmissionDirection(o_vec3 normal, o_vec3 incident, float incidentIOR, float transmittedIOR)
+{
+    float eta = incidentIOR / transmittedIOR;
+    float cosi = -dot3(normal, incident);
+    float sin2t = (eta * eta) * (1.0f - cosi * cosi);
+    if (sin2t > 1.0f) return v3(0, 0, 0);
+    float cost = sqrtf(1.0f - sin2t);
+    float k = eta * cosi - cost;
+    return add3(scale3(eta, incident), scale3(k, normal));
+}
+
+/* spec (ref stub: src/interactions.h:53-59): exact unpolarised dielectric Fresnel, 0.5*(rs^2 + rp^2) */
+o_Fresnel o_calculateFresnel(o_vec3 normal, o_vec3 incident, float incidentIOR, float transmittedIOR,
+                             o_vec3 reflectionDirection, o_vec3 transmissionDirection)
+{
+    o_Fresnel f;
+    (void)reflectionDirection;
+    if (transmissionDirection.x == 0.0f && transmissionDirection.y == 0.0f && transmissionDirection.z == 0.0f) {
+        f.reflectionCoefficient = 1.0f; f.transmissionCoefficient = 0.0f;     /* total internal reflection */
+        return f;
+    }
+    float cosi = -dot3(normal, incident);
+    float cost = -dot3(normal, transmissionDirection);
+    float rs = (incidentIOR * cosi - transmittedIOR * cost) / (incidentIOR * cosi + transmittedIOR * cost);
+    float rp = (transmittedIOR * cosi - incidentIOR * cost) / (transmittedIOR * cosi + incidentIOR * cost);
+    f.reflectionCoefficient = 0.5f * (rs * rs + rp * rp);
+    f.transmissionCoefficient = 1.0f - f.reflectionCoefficient;
+    return f;
+}
+
+/* spec (ref stub: src/interactions.h:97-104; material fields README.md:167-186, src/scene.cpp:236-258).
+ * Emission and absorption are handled by the caller; this picks the scattering lobe. */
+int o_calculateBSDF(o_ray *r, o_vec3 intersect, o_vec3 normal, o_vec3 *color, const o_material *m,
+                    float u_select, float xi1, float xi2, int trig_mode)
+{
+    o_vec3 d = r->direction;
+    float ndotd = dot3(normal, d);
+    int backside = (ndotd > 0.0f);
+    o_vec3 nf = backside ? neg3(normal) : normal;          /* shading normal faces the incident ray */
+
+    if (m->hasRefractive > 0.0f) {
+        float n1 = backside ? m->indexOfRefraction : 1.0f;
+        float n2 = backside ? 1.0f : m->indexOfRefraction;
+        o_vec3 refl = o_calculateReflectionDirection(nf, d);
+        o_vec3 trans = o_calculateTransmissionDirection(nf, d, n1, n2);
+        o_Fresnel f = o_calculateFresnel(nf, d, n1, n2, refl, trans);
+        *color = mul3(*color, m->specularColor);
+        if (u_select < f.reflectionCoefficient) {
+            r->origin = add3(intersect, scale3(O_RAY_BIAS_AMOUNT, nf));
+            r->direction = refl;
+            return 1;
+        }
+        r->origin = add3(intersect, scale3(O_RAY_BIAS_AMOUNT, neg3(nf)));
+        r->direction = trans;
+        return 2;
+    }
+    if (m->hasReflective > 0.0f) {
+        *color = mul3(*color, m->specularColor);
+        r->origin = add3(intersect, scale3(O_RAY_BIAS_AMOUNT, nf));
+        r->direction = o_calculateReflectionDirection(nf, d);
+        return 1;
+    }
+    *color = mul3(*color, m->color);
+    r->origin = add3(intersect, scale3(O_RAY_BIAS_AMOUNT, nf));
+    r->direction = o_calculateRandomDirectionInHemisphere(nf, xi1, xi2, trig_mode);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* raytraceKernel.cu                                                   */
+/* ------------------------------------------------------------------ */
+/* ref: src/raytraceKernel.cu:29-36 (index and the seed product are float arithmetic) */
+o_vec3 o_generateRandomNumberFromThread(o_vec2 resolution, float time, int x, int y)
+{
+    int index = (int)((float)x + ((float)y * resolution.x));
+    unsigned rng; o_minstd_seed(&rng, o_hash((unsigned)((float)index * time)));
+    float a = o_uniform_real(&rng, 0, 1), b = o_uniform_real(&rng, 0, 1), c = o_uniform_real(&rng, 0, 1);
+    return v3(a, b, c);
+}
+
+/* camera basis: the part of the camera ray that does not depend on the pixel (host-side in the product) */
+typedef struct { o_vec3 eye, M, H, V; float resx, resy; } cam_basis;
+static cam_basis camera_basis(o_vec2 resolution, o_vec3 eye, o_vec3 view, o_vec3 up, o_vec2 fov)
+{
+    cam_basis b;
+    o_vec3 A = normalize3(cross3(view, up));              /* screen-right */
+    o_vec3 B = normalize3(cross3(A, view));               /* screen-up */
+    float lenV = length3(view);
+    float tx = (float)tan((double)fov.x * (O_PI / 180.0));
+    float ty = (float)tan((double)fov.y * (O_PI / 180.0));
+    b.eye = eye;
+    b.M = add3(eye, view);
+    b.H = scale3(lenV * tx, A);
+    b.V = scale3(lenV * ty, B);
+    b.resx = resolution.x; b.resy = resolution.y;
+    return b;
+}
+static o_ray camera_ray(const cam_basis *b, int x, int y, float jx, float jy)
+{
+    float sx = ((float)x + jx) / b->resx;
+    float sy = ((float)y + jy) / b->resy;
+    /* buffer x=0 is screen-right and y=0 is the top row, so that the reference harness's flips
+     * (ref: src/main.cpp:120-125, 245-251) produce an unmirrored picture */
+    o_vec3 P = add3(add3(b->M, scale3(1.0f - 2.0f * sx, b->H)), scale3(1.0f - 2.0f * sy, b->V));
+    o_ray r;
+    r.origin = b->eye;
+    r.direction = normalize3(sub3(P, b->eye));
+    return r;
+}
+
+/* spec (ref stub: src/raytraceKernel.cu:38-45; fov convention src/scene.cpp:204-207): jittered pinhole
+ * camera.  `time` is the 1-based iteration the reference passes as (float)iterations (:149). */
+o_ray o_raycastFromCameraKernel(o_vec2 resolution, float time, int x, int y, o_vec3 eye, o_vec3 view,
+                                o_vec3 up, o_vec2 fov, unsigned seed)
+{
+    cam_basis b = camera_basis(resolution, eye, view, up, fov);
+    unsigned pixel = (unsigned)x + (unsigned)y * (unsigned)(int)resolution.x;
+    unsigned rng; o_minstd_seed(&rng, o_stream_seed(pixel, (unsigned)time, 0u, seed));
+    float jx = o_u01(&rng), jy = o_u01(&rng);
+    return camera_ray(&b, x, y, jx, jy);
+}
+
+/* ref: src/raytraceKernel.cu:58-89 (x255.0 in double, clamp above only, float->uchar truncation, w=0) */
+void o_sendImageToPBO(unsigned char *pbo, int npixels, const float *image)
+{
+    for (int i = 0; i < npixels; i++) {
+        float c[3];
+        for (int k = 0; k < 3; k++) {
+            c[k] = (float)((double)image[3 * i + k] * 255.0);
+            if (c[k] > 255) c[k] = 255;
+        }
+        pbo[4 * i + 3] = 0;
+        pbo[4 * i + 0] = (unsigned char)c[0];
+        pbo[4 * i + 1] = (unsigned char)c[1];
+        pbo[4 * i + 2] = (unsigned char)c[2];
+    }
+}
+
+/* ref: src/raytraceKernel.cu:48-55 */
+void o_clearImage(float *image, int npixels) { memset(image, 0, (size_t)npixels * 3 * sizeof(float)); }
+
+/* spec: nearest hit over the whole primitive list; smallest t > 0, ties -> lowest index */
+static int nearest_hit(const o_staticGeom *geoms, int nG, o_ray r, o_vec3 *p, o_vec3 *n)
+{
+    int best = -1; float best_t = 0;
+    for (int i = 0; i < nG; i++) {
+        o_vec3 ip, in; float t;
+        if (geoms[i].type == O_SPHERE) t = o_sphereIntersectionTest(&geoms[i], r, &ip, &in);
+        else if (geoms[i].type == O_CUBE) t = o_boxIntersectionTest(&geoms[i], r, &ip, &in);
+        else t = -1;                                      /* MESH: parsed, never loaded (ref: src/scene.cpp:57-66) */
+        if (t > 0 && (best < 0 || t < best_t)) { best = i; best_t = t; *p = ip; *n = in; }
+    }
+    return best;
+}
+
+/* spec: one path.  Returns the radiance sample L_i of this iteration. */
+static o_vec3 trace_path(const o_staticGeom *geoms, int nG, const o_material *mats, const cam_basis *cb,
+                         const o_options *opt, int W, int x, int y, unsigned iteration, int *bounces,
+                         unsigned long long *live_in)
+{
+    unsigned pixel = (unsigned)x + (unsigned)y * (unsigned)W;
+    unsigned rng; o_minstd_seed(&rng, o_stream_seed(pixel, iteration, 0u, opt->seed));
+    float jx = o_u01(&rng), jy = o_u01(&rng);
+    o_ray r = camera_ray(cb, x, y, jx, jy);
+    o_vec3 T = v3(1, 1, 1), L = v3(0, 0, 0);
+
+    for (int b = 0; b < opt->depth; b++) {
+        if (bounces) (*bounces)++;
+        if (live_in) live_in[b]++;
+        o_vec3 p, n;
+        int hit = nearest_hit(geoms, nG, r, &p, &n);
+        if (hit < 0) break;                                        /* background is black */
+        const o_material *m = &mats[geoms[hit].materialid];
+        if (m->emittance > 0.0f) {                                 /* light: emit and stop */
+            L = scale3(m->emittance, mul3(T, m->color));
+            break;
+        }
+        if (b == opt->depth - 1) break;                            /* depth exhausted: no contribution */
+
+        o_minstd_seed(&rng, o_stream_seed(pixel, iteration, (unsigned)b + 1u, opt->seed));
+        float u_select = o_u01(&rng), xi1 = o_u01(&rng), xi2 = o_u01(&rng), u_rr = o_u01(&rng);
+        o_calculateBSDF(&r, p, n, &T, m, u_select, xi1, xi2, opt->trig_mode);
+
+        if (opt->rr_start >= 0 && b >= opt->rr_start) {            /* Russian roulette */
+            float q = T.x;
+            if (T.y > q) q = T.y;
+            if (T.z > q) q = T.z;
+            q = (q < 0.05f) ? 0.05f : ((q > 1.0f) ? 1.0f : q);
+            if (u_rr >= q) break;
+            T = v3(T.x / q, T.y / q, T.z / q);
+        }
+    }
+    return L;
+}
+
+static int validate(const o_staticGeom *geoms, int nG, int nM, const o_cameraData *cam, const o_options *opt)
+{
+    if (!cam || !opt || nG < 0 || nM < 0 || (nG > 0 && !geoms)) return -1;
+    if (opt->depth < 1 || (int)cam->resolution.x < 1 || (int)cam->resolution.y < 1) return -2;
+    for (int i = 0; i < nG; i++)
+        if (geoms[i].type != O_MESH && (geoms[i].materialid < 0 || geoms[i].materialid >= nM)) return -3;
+    return 0;
+}
+
+o_vec3 o_trace_path(const o_staticGeom *geoms, int nG, const o_material *mats, int nM, const o_cameraData *cam,
+                    const o_options *opt, int x, int y, unsigned iteration, int *bounces_out)
+{
+    if (validate(geoms, nG, nM, cam, opt) != 0) return v3(-1, -1, -1);
+    cam_basis cb = camera_basis(cam->resolution, cam->position, cam->view, cam->up, cam->fov);
+    if (bounces_out) *bounces_out = 0;
+    return trace_path(geoms, nG, mats, &cb, opt, (int)cam->resolution.x, x, y, iteration, bounces_out, NULL);
+}
+
+typedef struct {
+    const o_staticGeom *geoms; int nG; const o_material *mats; const cam_basis *cb; const o_options *opt;
+    float *image; int W, H; int iter_first, iter_count; int row0, row1;
+    unsigned long long *live_in;   /* private per thread, depth entries */
+} job;
+
+static void *render_rows(void *arg)
+{
+    job *j = (job *)arg;
+    for (int it = j->iter_first; it < j->iter_first + j->iter_count; it++) {
+        for (int y = j->row0; y < j->row1; y++) {
+            for (int x = 0; x < j->W; x++) {
+                o_vec3 L = trace_path(j->geoms, j->nG, j->mats, j->cb, j->opt, j->W, x, y, (unsigned)it,
+                                      NULL, j->live_in);
+                /* spec: running mean, stateless given (image, iteration) */
+                float *px = &j->image[3 * ((size_t)x + (size_t)y * (size_t)j->W)];
+                float fi = (float)it, fim1 = (float)(it - 1);
+                px[0] = (px[0] * fim1 + L.x) / fi;
+                px[1] = (px[1] * fim1 + L.y) / fi;
+                px[2] = (px[2] * fim1 + L.z) / fi;
+            }
+        }
+    }
+    return NULL;
+}
+
+int o_render(const o_staticGeom *geoms, int nG, const o_material *mats, int nM, const o_cameraData *cam,
+             const o_options *opt, float *image, int iter_first, int iter_count,
+             unsigned long long *live_in, int nthreads)
+{
+    int rc = validate(geoms, nG, nM, cam, opt);
+    if (rc != 0) return rc;
+    if (!image || iter_first < 1 || iter_count < 0) return -4;
+    int W = (int)cam->resolution.x, H = (int)cam->resolution.y;
+    cam_basis cb = camera_basis(cam->resolution, cam->position, cam->view, cam->up, cam->fov);
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > H) nthreads = H;
+    if (nthreads > 256) nthreads = 256;
+
+    job jobs[256]; pthread_t th[256];
+    unsigned long long *counts = (unsigned long long *)calloc((size_t)nthreads * (size_t)opt->depth, sizeof(*counts));
+    if (!counts) return -5;
+    /* rows are dealt in contiguous blocks; each pixel is owned by exactly one thread */
+    for (int t = 0; t < nthreads; t++) {
+        job *j = &jobs[t];
+        j->geoms = geoms; j->nG = nG; j->mats = mats; j->cb = &cb; j->opt = opt; j->image = image;
+        j->W = W; j->H = H; j->iter_first = iter_first; j->iter_count = iter_count;
+        j->row0 = (int)((long long)H * t / nthreads); j->row1 = (int)((long long)H * (t + 1) / nthreads);
+        j->live_in = counts + (size_t)t * (size_t)opt->depth;
+    }
+    if (nthreads == 1) render_rows(&jobs[0]);
+    else {
+        for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, render_rows, &jobs[t]);
+        for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    }
+    if (live_in)
+        for (int b = 0; b < opt->depth; b++) {
+            unsigned long long s = 0;
+            for (int t = 0; t < nthreads; t++) s += counts[(size_t)t * (size_t)opt->depth + (size_t)b];
+            live_in[b] += s;
+        }
+    free(counts);
+    return 0;
+}
