@@ -1,0 +1,169 @@
+/*
+ * pt_abi.h -- C-ABI of the MI355X-native path-tracing renderer (libptamd.so).
+ *
+ * This is the drop-in boundary for the reference's renderer entry point
+ *     void cudaRaytraceCore(uchar4* pos, camera* renderCam, int frame, int iterations,
+ *                           material* materials, int numberOfMaterials, geom* geoms, int numberOfGeoms);
+ * (ref: src/raytraceKernel.h:17, body src/raytraceKernel.cu:106-165).  That symbol is C++-mangled and its
+ * `camera` argument holds a std::string (ref: src/sceneStructs.h:50-61), so it cannot itself be a C-ABI.
+ * The reference-side binding is a ~40-line C++ shim with that exact signature which flattens the
+ * arguments exactly as src/raytraceKernel.cu:123-146 does and calls the functions below
+ * (shown in INTEGRATION.md, shipped as project3-pathtracer_amd/csrc/pt_shim.cpp).
+ *
+ * Everything here is POD: plain pointers, ints, floats.  No torch, HIP or C++ types in any signature
+ * (the stream / device pointers are passed as void*).  All functions return PT_OK (0) or a negative
+ * pt_status; pt_last_error() gives the message of the calling thread's last failure.  Nothing below the
+ * shim ever calls exit() (the reference's checkCUDAError does, ref: src/raytraceKernel.cu:19-25; the shim
+ * keeps that behaviour for drop-in parity).
+ *
+ * There is NO CPU fallback: without a usable gfx950 device pt_create() fails with PT_ERR_NO_DEVICE.
+ */
+#ifndef PT_ABI_H
+#define PT_ABI_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1
+#define PT_MAX_DEPTH 64
+
+typedef enum pt_status {
+    PT_OK = 0,
+    PT_ERR_INVALID = -1,      /* bad argument / call order */
+    PT_ERR_NO_DEVICE = -2,    /* no gfx950 device or HIP runtime failure at create */
+    PT_ERR_HIP = -3,          /* a HIP call failed; message in pt_last_error() */
+    PT_ERR_OOM = -4
+} pt_status;
+
+/* ---- POD layouts: byte-identical to the reference's device structs (x86-64), so a caller can pass its
+ *      own arrays unchanged.  Sizes/offsets are pinned by tests/test_abi.py against
+ *      tests/golden/reference_vectors.json "layouts". ---- */
+typedef struct pt_vec2 { float x, y; } pt_vec2;
+typedef struct pt_vec3 { float x, y, z; } pt_vec3;
+typedef struct pt_vec4 { float x, y, z, w; } pt_vec4;
+typedef struct pt_mat4 { pt_vec4 x, y, z, w; } pt_mat4;             /* cudaMat4: four ROWS, ref: src/cudaMat4.h:18-23 */
+typedef struct pt_uchar4 { unsigned char x, y, z, w; } pt_uchar4;   /* PBO texel, ref: src/raytraceKernel.cu:83-87 */
+
+enum { PT_SPHERE = 0, PT_CUBE = 1, PT_MESH = 2 };                   /* GEOMTYPE, ref: src/sceneStructs.h:14 */
+
+typedef struct pt_static_geom {                                     /* staticGeom, ref: src/sceneStructs.h:32-40, 172 B */
+    int type;
+    int materialid;
+    pt_vec3 translation, rotation, scale;                           /* carried, never read by the renderer */
+    pt_mat4 transform, inverseTransform;
+} pt_static_geom;
+
+typedef struct pt_material {                                        /* material, ref: src/sceneStructs.h:63-74, 64 B */
+    pt_vec3 color;
+    float specularExponent;
+    pt_vec3 specularColor;
+    float hasReflective;
+    float hasRefractive;
+    float indexOfRefraction;
+    float hasScatter;
+    pt_vec3 absorptionCoefficient;
+    float reducedScatterCoefficient;
+    float emittance;
+} pt_material;
+
+typedef struct pt_camera_data {                                     /* cameraData, ref: src/sceneStructs.h:42-48, 52 B */
+    pt_vec2 resolution;
+    pt_vec3 position, view, up;
+    pt_vec2 fov;                                                    /* degrees, half-angles (ref: src/scene.cpp:204-207) */
+} pt_camera_data;
+
+/* Knobs the reference keeps as source constants (trace depth, ref: src/raytraceKernel.cu:110) or does not
+ * have at all.  pt_default_options() fills the defaults. */
+typedef struct pt_options {
+    int depth;            /* bounces per path, 1..PT_MAX_DEPTH (default 8) */
+    int rr_start;         /* first bounce with Russian roulette, <0 = off (default -1) */
+    unsigned seed;        /* RNG stream selector (default 0) */
+    int compaction;       /* 1 = compact live rays after every bounce (default), 0 = rays keep their slot */
+    int workgroup;        /* threads per workgroup: 64, 128, 256, 512 or 1024 (default 0 = library choice) */
+    int geom_path;        /* 0 = primitives through scalar (SGPR) loads, 1 = primitives staged in LDS (default 0) */
+    int row_begin;        /* tile rendered by this context: rows [row_begin, row_end) of the frame; */
+    int row_end;          /*   0,0 = the whole frame.  RNG streams are keyed on the global pixel index. */
+    int use_graph;        /* 1 = replay one captured hipGraph per iteration (default), 0 = eager launches */
+    int reserved[7];
+} pt_options;
+
+typedef struct pt_stats {
+    unsigned long long iterations;             /* iterations rendered since create / pt_reset_stats */
+    unsigned long long ray_bounces;            /* sum over iterations and bounces of live rays entering the bounce */
+    unsigned long long live_in[PT_MAX_DEPTH];  /* the same, per bounce */
+    double gpu_ms;                             /* HIP-event time of all pt_render calls on the render stream */
+    unsigned long long bounce_launches;        /* per-bounce kernel launches inside those calls */
+} pt_stats;
+
+typedef struct pt_ctx pt_ctx;
+
+/* ---- lifetime ---- */
+int  pt_device_count(void);
+int  pt_create(int device, pt_ctx **out);             /* persistent device context (replaces the per-call
+                                                         cudaMalloc/cudaFree of ref: src/raytraceKernel.cu:118-158) */
+void pt_destroy(pt_ctx *ctx);
+const char *pt_last_error(void);
+const char *pt_version(void);
+
+/* ---- inputs (replaces ref: src/raytraceKernel.cu:123-146) ---- */
+void pt_default_options(pt_options *opt);
+int  pt_set_options(pt_ctx *ctx, const pt_options *opt);
+int  pt_get_options(pt_ctx *ctx, pt_options *opt);
+int  pt_set_scene(pt_ctx *ctx, const pt_static_geom *geoms, int numberOfGeoms,
+                  const pt_material *materials, int numberOfMaterials);
+int  pt_set_camera(pt_ctx *ctx, const pt_camera_data *cam);
+int  pt_set_stream(pt_ctx *ctx, void *hip_stream);    /* render on a caller-owned hipStream_t; NULL = own stream */
+
+/* ---- framebuffer: fp32 RGB, 12 B/pixel, index = x + y*W (ref: src/raytraceKernel.cu:98), tile rows only.
+ *      It always holds the running mean over the iterations rendered so far. ---- */
+size_t pt_image_bytes(pt_ctx *ctx);
+int  pt_bind_image(pt_ctx *ctx, void *device_rgb);    /* render into caller-owned device memory (>= pt_image_bytes);
+                                                         NULL = library-owned buffer */
+int  pt_clear_image(pt_ctx *ctx);                     /* clearImage, ref: src/raytraceKernel.cu:48-55 */
+int  pt_upload_image(pt_ctx *ctx, const float *host_rgb);    /* H2D, ref: src/raytraceKernel.cu:120 */
+int  pt_download_image(pt_ctx *ctx, float *host_rgb);        /* D2H (synchronous), ref: src/raytraceKernel.cu:154 */
+
+/* ---- the hot path ---- */
+/* Enqueue iterations [iter_first, iter_first + iter_count) (1-based, as ref: src/main.cpp:95 passes them):
+ * camera rays (raycastFromCameraKernel), per-bounce intersect/shade (raytraceRay) and live-ray compaction.
+ * Asynchronous on the render stream. */
+int  pt_render(pt_ctx *ctx, int iter_first, int iter_count);
+/* sendImageToPBO (ref: src/raytraceKernel.cu:58-89): fp32 RGB x255, clamp, RGBA8 into a DEVICE buffer of
+ * tile pixels.  Asynchronous on the render stream. */
+int  pt_send_image_to_pbo(pt_ctx *ctx, pt_uchar4 *device_pbo);
+int  pt_synchronize(pt_ctx *ctx);                     /* cudaThreadSynchronize, ref: src/raytraceKernel.cu:162 */
+
+/* One reference-style iteration: optional H2D of host_image_inout when iteration > 1 and the context has no
+ * accumulated state, render `iteration`, optional PBO, D2H into host_image_inout (if non-NULL), synchronize. */
+int  pt_render_iteration(pt_ctx *ctx, pt_uchar4 *device_pbo_or_null, float *host_image_inout_or_null, int iteration);
+
+/* ---- measurement ---- */
+int  pt_get_stats(pt_ctx *ctx, pt_stats *out);        /* synchronizes the render stream */
+int  pt_reset_stats(pt_ctx *ctx);
+
+/* ---- scene files (ref: src/scene.cpp, src/utilities.cpp:74-90; format README.md:160-217) ---- */
+enum { PT_ROTAT_RADIANS = 0,   /* what the reference binary does (GLM_FORCE_RADIANS, ref: src/utilities.cpp:7) */
+       PT_ROTAT_DEGREES = 1 }; /* what the scene author evidently meant */
+typedef struct pt_scene pt_scene;
+int  pt_scene_load(const char *path, int rotat_units, pt_scene **out);
+void pt_scene_free(pt_scene *s);
+int  pt_scene_counts(const pt_scene *s, int *n_objects, int *n_materials, int *n_camera_frames);
+int  pt_scene_camera_info(const pt_scene *s, unsigned *iterations, char *image_name, size_t image_name_cap);
+/* flatten frame `frame` into the POD arrays above (what ref: src/raytraceKernel.cu:123-146 does) */
+int  pt_scene_get_frame(const pt_scene *s, int frame, pt_static_geom *geoms_out, pt_material *materials_out,
+                        pt_camera_data *camera_out);
+/* RES override: recomputes fov.x from fov.y as the loader does (ref: src/scene.cpp:204-207) */
+int  pt_camera_set_resolution(pt_camera_data *cam, int width, int height);
+
+/* ---- end-of-render image write-out (ref: src/main.cpp:116-141, src/image.cpp:41-88): horizontal flip
+ *      buffer (x,y) -> picture (W-1-x, y), gamma 1.0, clamp(v*255, 0, 255) truncation ---- */
+int  pt_image_to_rgb8(const float *host_rgb, int width, int height, int flip_x, unsigned char *rgb8_out);
+int  pt_save_image_bmp(const char *path, const float *host_rgb, int width, int height, int flip_x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_ABI_H */

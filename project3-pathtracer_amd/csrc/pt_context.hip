@@ -1,0 +1,543 @@
+// pt_context.hip -- host side of the C-ABI (include/pt_abi.h): persistent device context, scene/camera
+// flattening, launch sequencing, hipGraph capture, event timing.
+//
+// Replaces the host body of cudaRaytraceCore (ref: src/raytraceKernel.cu:106-165): instead of
+// cudaMalloc + H2D + 2 launches + D2H + cudaFree on every iteration, the context keeps the framebuffer,
+// ray pools and scene resident and enqueues 1 + depth launches per iteration with no host round trip.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "pt_internal.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return fail(PT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+struct v3 { float x, y, z; };
+v3 cross3(v3 x, v3 y) { return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y}; }
+v3 normalize3(v3 v)
+{
+    float inv = 1.0f / sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    return {v.x * inv, v.y * inv, v.z * inv};
+}
+float length3(v3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
+
+}  // namespace
+
+struct pt_ctx {
+    int device = 0;
+    int cu_count = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+
+    pt_options opt;
+    bool have_scene = false, have_camera = false;
+    std::vector<pt_static_geom> geoms;
+    std::vector<pt_material> mats;
+    pt_camera_data cam;
+
+    // device state
+    bool dirty = true;          // scene / camera / options changed since the last configure
+    pt::KParams kp;
+    pt::LaunchCfg cfg;
+    ptd::Prim *d_prims = nullptr;
+    float *d_mats = nullptr;
+    float *d_image_own = nullptr;
+    float *d_image_bound = nullptr;
+    size_t image_bytes = 0, image_cap = 0;
+    void *d_pool = nullptr;
+    size_t pool_cap = 0;
+    pt::IterState *d_state = nullptr;
+    bool image_valid = false;   // framebuffer holds iterations 1..k of the current frame
+
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timers;
+    double gpu_ms = 0.0;
+    unsigned long long bounce_launches = 0;
+};
+
+namespace {
+
+void drop_graph(pt_ctx *c)
+{
+    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+}
+
+int fold_timers(pt_ctx *c)
+{
+    for (auto &t : c->timers) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventSynchronize(t.second));
+        HIP_TRY(hipEventElapsedTime(&ms, t.first, t.second));
+        c->gpu_ms += (double)ms;
+        (void)hipEventDestroy(t.first);
+        (void)hipEventDestroy(t.second);
+    }
+    c->timers.clear();
+    return PT_OK;
+}
+
+float *image_ptr(pt_ctx *c) { return c->d_image_bound ? c->d_image_bound : c->d_image_own; }
+
+// (re)build everything that depends on scene, camera or options
+int configure(pt_ctx *c)
+{
+    if (!c->have_scene) return fail(PT_ERR_INVALID, "pt_set_scene has not been called");
+    if (!c->have_camera) return fail(PT_ERR_INVALID, "pt_set_camera has not been called");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->dirty) return PT_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drop_graph(c);
+
+    const pt_options &o = c->opt;
+    const int W = (int)c->cam.resolution.x, H = (int)c->cam.resolution.y;
+    if (W < 1 || H < 1) return fail(PT_ERR_INVALID, "camera resolution %dx%d", W, H);
+    int r0 = o.row_begin, r1 = o.row_end;
+    if (r0 == 0 && r1 == 0) r1 = H;
+    if (r0 < 0 || r1 > H || r0 >= r1) return fail(PT_ERR_INVALID, "tile rows [%d,%d) outside frame height %d", r0, r1, H);
+    const long long npix_ll = (long long)W * (long long)(r1 - r0);
+    if ((long long)W * (long long)H > 0x7FFFFFFFLL / 4) return fail(PT_ERR_INVALID, "frame %dx%d too large", W, H);
+    const int npix = (int)npix_ll;
+
+    pt::KParams &k = c->kp;
+    memset(&k, 0, sizeof k);
+
+    // camera basis: pixel-independent part of raycastFromCameraKernel (DESIGN.md "Canonical semantics", camera)
+    {
+        const v3 eye = {c->cam.position.x, c->cam.position.y, c->cam.position.z};
+        const v3 view = {c->cam.view.x, c->cam.view.y, c->cam.view.z};
+        const v3 up = {c->cam.up.x, c->cam.up.y, c->cam.up.z};
+        const v3 A = normalize3(cross3(view, up));
+        const v3 B = normalize3(cross3(A, view));
+        const float lenV = length3(view);
+        const double PI = 3.1415926535897932384626422832795028841971;
+        const float tx = (float)tan((double)c->cam.fov.x * (PI / 180.0));
+        const float ty = (float)tan((double)c->cam.fov.y * (PI / 180.0));
+        const float hx = lenV * tx, vy = lenV * ty;
+        k.eye[0] = eye.x; k.eye[1] = eye.y; k.eye[2] = eye.z;
+        k.M[0] = eye.x + view.x; k.M[1] = eye.y + view.y; k.M[2] = eye.z + view.z;
+        k.H[0] = hx * A.x; k.H[1] = hx * A.y; k.H[2] = hx * A.z;
+        k.V[0] = vy * B.x; k.V[1] = vy * B.y; k.V[2] = vy * B.z;
+        k.resx = c->cam.resolution.x; k.resy = c->cam.resolution.y;
+    }
+    k.W = W;
+    k.row_begin = r0;
+    k.npix = npix;
+    k.pix_offset = (uint32_t)r0 * (uint32_t)W;
+    k.nG = (int)c->geoms.size();
+    k.nM = (int)c->mats.size();
+    k.depth = o.depth;
+    k.rr_start = o.rr_start;
+    k.seed = o.seed;
+
+    // scene -> device records
+    {
+        std::vector<ptd::Prim> prims(c->geoms.size() ? c->geoms.size() : 1);
+        memset(prims.data(), 0, prims.size() * sizeof(ptd::Prim));
+        for (size_t i = 0; i < c->geoms.size(); ++i) {
+            const pt_static_geom &g = c->geoms[i];
+            ptd::Prim &p = prims[i];
+            p.type = (uint32_t)g.type;
+            p.material = (uint32_t)g.materialid;
+            memcpy(p.inv, &g.inverseTransform, 12 * sizeof(float));
+            memcpy(p.fwd, &g.transform, 12 * sizeof(float));
+            // multiplyMV(transform, (0,0,0,1)) with the reference's operation order (ref: src/intersections.h:53-59,111)
+            const pt_mat4 &m = g.transform;
+            p.cx = (m.x.x * 0.0f) + (m.x.y * 0.0f) + (m.x.z * 0.0f) + (m.x.w * 1.0f);
+            p.cy = (m.y.x * 0.0f) + (m.y.y * 0.0f) + (m.y.z * 0.0f) + (m.y.w * 1.0f);
+            p.cz = (m.z.x * 0.0f) + (m.z.y * 0.0f) + (m.z.z * 0.0f) + (m.z.w * 1.0f);
+        }
+        if (c->d_prims) { (void)hipFree(c->d_prims); c->d_prims = nullptr; }
+        HIP_TRY(hipMalloc((void **)&c->d_prims, prims.size() * sizeof(ptd::Prim)));
+        HIP_TRY(hipMemcpy(c->d_prims, prims.data(), prims.size() * sizeof(ptd::Prim), hipMemcpyHostToDevice));
+
+        const size_t nM = c->mats.size();
+        std::vector<float> planes((nM ? nM : 1) * ptd::M_PLANES, 0.0f);
+        for (size_t i = 0; i < nM; ++i) {
+            const pt_material &m = c->mats[i];
+            planes[ptd::M_CR * nM + i] = m.color.x; planes[ptd::M_CG * nM + i] = m.color.y; planes[ptd::M_CB * nM + i] = m.color.z;
+            planes[ptd::M_SR * nM + i] = m.specularColor.x; planes[ptd::M_SG * nM + i] = m.specularColor.y;
+            planes[ptd::M_SB * nM + i] = m.specularColor.z;
+            planes[ptd::M_REFL * nM + i] = m.hasReflective; planes[ptd::M_REFR * nM + i] = m.hasRefractive;
+            planes[ptd::M_IOR * nM + i] = m.indexOfRefraction; planes[ptd::M_EMIT * nM + i] = m.emittance;
+        }
+        if (c->d_mats) { (void)hipFree(c->d_mats); c->d_mats = nullptr; }
+        HIP_TRY(hipMalloc((void **)&c->d_mats, planes.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(c->d_mats, planes.data(), planes.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    k.prims = c->d_prims;
+    k.mats = c->d_mats;
+
+    // framebuffer
+    const size_t img_bytes = (size_t)npix * 3 * sizeof(float);
+    if (img_bytes != c->image_bytes) c->image_valid = false;
+    c->image_bytes = img_bytes;
+    if (!c->d_image_bound && c->image_cap < img_bytes) {
+        if (c->d_image_own) (void)hipFree(c->d_image_own);
+        c->d_image_own = nullptr; c->image_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c->d_image_own, img_bytes));
+        c->image_cap = img_bytes;
+        HIP_TRY(hipMemset(c->d_image_own, 0, img_bytes));
+        c->image_valid = false;
+    }
+    k.image = image_ptr(c);
+
+    // ray pools: 2 x npix x 40 B, carved from one allocation
+    const size_t npad = ((size_t)npix + 63) & ~(size_t)63;
+    const size_t one = npad * (16 + 16 + 8);
+    if (c->pool_cap < 2 * one) {
+        if (c->d_pool) (void)hipFree(c->d_pool);
+        c->d_pool = nullptr; c->pool_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_pool, 2 * one));
+        c->pool_cap = 2 * one;
+    }
+    for (int q = 0; q < 2; ++q) {
+        unsigned char *base = (unsigned char *)c->d_pool + (size_t)q * one;
+        k.pool[q].a = (float4 *)base;
+        k.pool[q].b = (float4 *)(base + npad * 16);
+        k.pool[q].c = (float2 *)(base + npad * 32);
+    }
+    k.st = c->d_state;
+
+    // launch shape: persistent workgroups, as many as are resident at once
+    pt::LaunchCfg &cfg = c->cfg;
+    cfg.workgroup = o.workgroup ? o.workgroup : 256;
+    cfg.geom_lds = o.geom_path == 1;
+    cfg.compact = o.compaction != 0;
+    const size_t lds = pt::bounce_lds_bytes(k, cfg);
+    if (lds > 160 * 1024) return fail(PT_ERR_INVALID, "scene needs %zu B of LDS per workgroup (> 160 KiB)", lds);
+    int per_cu = pt::bounce_max_blocks_per_cu(k, cfg);
+    if (per_cu < 1) return fail(PT_ERR_HIP, "occupancy query failed for workgroup=%d (%s)", cfg.workgroup,
+                                hipGetErrorString(hipGetLastError()));
+    const long long want = ((long long)npix + cfg.workgroup - 1) / cfg.workgroup;
+    long long grid = (long long)c->cu_count * per_cu;
+    if (grid > want) grid = want;
+    if (grid < 1) grid = 1;
+    cfg.grid = (int)grid;
+
+    c->dirty = false;
+    return PT_OK;
+}
+
+int enqueue_iteration(pt_ctx *c, hipStream_t s)
+{
+    HIP_TRY(pt::launch_iter_begin(s, c->d_state, c->kp.npix, c->kp.depth, c->cfg.compact));
+    for (int b = 0; b < c->kp.depth; ++b) HIP_TRY(pt::launch_bounce(s, c->kp, c->cfg, b));
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pt_last_error(void) { return g_last_error.c_str(); }
+const char *pt_version(void) { return "ptamd 0.1 (gfx950, abi 1)"; }
+
+int pt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void pt_default_options(pt_options *o)
+{
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->depth = 8;
+    o->rr_start = -1;
+    o->seed = 0;
+    o->compaction = 1;
+    o->workgroup = 0;
+    o->geom_path = 0;
+    o->use_graph = 1;
+}
+
+int pt_create(int device, pt_ctx **out)
+{
+    if (!out) return fail(PT_ERR_INVALID, "pt_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n < 1)
+        return fail(PT_ERR_NO_DEVICE, "no HIP device (%s); this renderer has no CPU path", hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(PT_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PT_ERR_NO_DEVICE, "device %d is %s; kernels are built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device));
+    pt_ctx *c = new pt_ctx();
+    c->device = device;
+    c->cu_count = prop.multiProcessorCount;
+    pt_default_options(&c->opt);
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(PT_ERR_HIP, "hipStreamCreate failed");
+    }
+    c->stream = c->own_stream;
+    if (hipMalloc((void **)&c->d_state, sizeof(pt::IterState)) != hipSuccess ||
+        hipMemset(c->d_state, 0, sizeof(pt::IterState)) != hipSuccess) {
+        pt_destroy(c);
+        return fail(PT_ERR_OOM, "cannot allocate iteration state");
+    }
+    *out = c;
+    return PT_OK;
+}
+
+void pt_destroy(pt_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    drop_graph(c);
+    for (auto &t : c->timers) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }
+    if (c->d_prims) (void)hipFree(c->d_prims);
+    if (c->d_mats) (void)hipFree(c->d_mats);
+    if (c->d_image_own) (void)hipFree(c->d_image_own);
+    if (c->d_pool) (void)hipFree(c->d_pool);
+    if (c->d_state) (void)hipFree(c->d_state);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int pt_set_options(pt_ctx *c, const pt_options *o)
+{
+    if (!c || !o) return fail(PT_ERR_INVALID, "pt_set_options: NULL argument");
+    if (o->depth < 1 || o->depth > PT_MAX_DEPTH) return fail(PT_ERR_INVALID, "depth %d not in 1..%d", o->depth, PT_MAX_DEPTH);
+    const int wg = o->workgroup;
+    if (!(wg == 0 || wg == 64 || wg == 128 || wg == 256 || wg == 512 || wg == 1024))
+        return fail(PT_ERR_INVALID, "workgroup %d not one of 0,64,128,256,512,1024", wg);
+    if (o->geom_path != 0 && o->geom_path != 1) return fail(PT_ERR_INVALID, "geom_path %d not 0 or 1", o->geom_path);
+    if (o->row_begin < 0 || o->row_end < o->row_begin) return fail(PT_ERR_INVALID, "tile rows [%d,%d)", o->row_begin, o->row_end);
+    c->opt = *o;
+    c->dirty = true;
+    return PT_OK;
+}
+
+int pt_get_options(pt_ctx *c, pt_options *o)
+{
+    if (!c || !o) return fail(PT_ERR_INVALID, "pt_get_options: NULL argument");
+    *o = c->opt;
+    return PT_OK;
+}
+
+int pt_set_scene(pt_ctx *c, const pt_static_geom *geoms, int nG, const pt_material *mats, int nM)
+{
+    if (!c || nG < 0 || nM < 0 || (nG > 0 && !geoms) || (nM > 0 && !mats))
+        return fail(PT_ERR_INVALID, "pt_set_scene: bad arguments (nG=%d nM=%d)", nG, nM);
+    for (int i = 0; i < nG; ++i) {
+        if (geoms[i].type < PT_SPHERE || geoms[i].type > PT_MESH)
+            return fail(PT_ERR_INVALID, "geom %d: type %d is not SPHERE/CUBE/MESH", i, geoms[i].type);
+        if (geoms[i].type != PT_MESH && (geoms[i].materialid < 0 || geoms[i].materialid >= nM))
+            return fail(PT_ERR_INVALID, "geom %d: materialid %d outside 0..%d", i, geoms[i].materialid, nM - 1);
+    }
+    c->geoms.assign(geoms, geoms + nG);
+    c->mats.assign(mats, mats + nM);
+    c->have_scene = true;
+    c->dirty = true;
+    return PT_OK;
+}
+
+int pt_set_camera(pt_ctx *c, const pt_camera_data *cam)
+{
+    if (!c || !cam) return fail(PT_ERR_INVALID, "pt_set_camera: NULL argument");
+    if (!(cam->resolution.x >= 1.0f) || !(cam->resolution.y >= 1.0f))
+        return fail(PT_ERR_INVALID, "camera resolution %gx%g", cam->resolution.x, cam->resolution.y);
+    c->cam = *cam;
+    c->have_camera = true;
+    c->dirty = true;
+    return PT_OK;
+}
+
+int pt_set_stream(pt_ctx *c, void *hip_stream)
+{
+    if (!c) return fail(PT_ERR_INVALID, "pt_set_stream: NULL context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (fold_timers(c) != PT_OK) return PT_ERR_HIP;
+    drop_graph(c);
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return PT_OK;
+}
+
+size_t pt_image_bytes(pt_ctx *c)
+{
+    if (!c || !c->have_camera) return 0;
+    const int W = (int)c->cam.resolution.x, H = (int)c->cam.resolution.y;
+    int r0 = c->opt.row_begin, r1 = c->opt.row_end;
+    if (r0 == 0 && r1 == 0) r1 = H;
+    if (r1 > H || r0 >= r1) return 0;
+    return (size_t)W * (size_t)(r1 - r0) * 3 * sizeof(float);
+}
+
+int pt_bind_image(pt_ctx *c, void *device_rgb)
+{
+    if (!c) return fail(PT_ERR_INVALID, "pt_bind_image: NULL context");
+    c->d_image_bound = (float *)device_rgb;
+    c->image_valid = false;
+    c->dirty = true;
+    return PT_OK;
+}
+
+int pt_clear_image(pt_ctx *c)
+{
+    if (!c) return fail(PT_ERR_INVALID, "pt_clear_image: NULL context");
+    int rc = configure(c);
+    if (rc != PT_OK) return rc;
+    HIP_TRY(hipMemsetAsync(image_ptr(c), 0, c->image_bytes, c->stream));
+    c->image_valid = false;
+    return PT_OK;
+}
+
+int pt_upload_image(pt_ctx *c, const float *host_rgb)
+{
+    if (!c || !host_rgb) return fail(PT_ERR_INVALID, "pt_upload_image: NULL argument");
+    int rc = configure(c);
+    if (rc != PT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(image_ptr(c), host_rgb, c->image_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->image_valid = true;
+    return PT_OK;
+}
+
+int pt_download_image(pt_ctx *c, float *host_rgb)
+{
+    if (!c || !host_rgb) return fail(PT_ERR_INVALID, "pt_download_image: NULL argument");
+    int rc = configure(c);
+    if (rc != PT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(host_rgb, image_ptr(c), c->image_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_render(pt_ctx *c, int iter_first, int iter_count)
+{
+    if (!c) return fail(PT_ERR_INVALID, "pt_render: NULL context");
+    if (iter_first < 1 || iter_count < 0) return fail(PT_ERR_INVALID, "pt_render: iterations [%d,+%d)", iter_first, iter_count);
+    int rc = configure(c);
+    if (rc != PT_OK) return rc;
+    if (iter_count == 0) return PT_OK;
+    hipStream_t s = c->stream;
+
+    if (c->timers.size() >= 1024) { rc = fold_timers(c); if (rc != PT_OK) return rc; }
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    c->timers.emplace_back(e0, e1);
+    HIP_TRY(hipEventRecord(e0, s));
+
+    HIP_TRY(pt::launch_iter_set(s, c->d_state, (uint32_t)(iter_first - 1)));
+    if (c->opt.use_graph) {
+        if (!c->graph_exec) {
+            HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            rc = enqueue_iteration(c, s);
+            hipError_t ce = hipStreamEndCapture(s, &c->graph);
+            if (rc != PT_OK) { drop_graph(c); return rc; }
+            if (ce != hipSuccess) { drop_graph(c); return fail(PT_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce)); }
+            HIP_TRY(hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+        }
+        for (int i = 0; i < iter_count; ++i) HIP_TRY(hipGraphLaunch(c->graph_exec, s));
+    } else {
+        for (int i = 0; i < iter_count; ++i) { rc = enqueue_iteration(c, s); if (rc != PT_OK) return rc; }
+    }
+    HIP_TRY(pt::launch_iter_fold(s, c->d_state, c->kp.depth));
+    HIP_TRY(hipEventRecord(e1, s));
+    c->bounce_launches += (unsigned long long)iter_count * (unsigned long long)c->kp.depth;
+    c->image_valid = true;
+    return PT_OK;
+}
+
+int pt_send_image_to_pbo(pt_ctx *c, pt_uchar4 *device_pbo)
+{
+    if (!c || !device_pbo) return fail(PT_ERR_INVALID, "pt_send_image_to_pbo: NULL argument");
+    int rc = configure(c);
+    if (rc != PT_OK) return rc;
+    HIP_TRY(pt::launch_send_image_to_pbo(c->stream, device_pbo, image_ptr(c), c->kp.npix));
+    return PT_OK;
+}
+
+int pt_synchronize(pt_ctx *c)
+{
+    if (!c) return fail(PT_ERR_INVALID, "pt_synchronize: NULL context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+int pt_render_iteration(pt_ctx *c, pt_uchar4 *pbo, float *host_image, int iteration)
+{
+    if (!c) return fail(PT_ERR_INVALID, "pt_render_iteration: NULL context");
+    int rc = configure(c);
+    if (rc != PT_OK) return rc;
+    // The running mean is stateless given (image, iteration) (ref: src/raytraceKernel.cu:120,154): a context
+    // that has not rendered iterations 1..iteration-1 itself takes them from the caller's buffer.
+    if (iteration > 1 && !c->image_valid && host_image) {
+        rc = pt_upload_image(c, host_image);
+        if (rc != PT_OK) return rc;
+    }
+    rc = pt_render(c, iteration, 1);
+    if (rc != PT_OK) return rc;
+    if (pbo) { rc = pt_send_image_to_pbo(c, pbo); if (rc != PT_OK) return rc; }
+    if (host_image) return pt_download_image(c, host_image);
+    return pt_synchronize(c);
+}
+
+int pt_get_stats(pt_ctx *c, pt_stats *out)
+{
+    if (!c || !out) return fail(PT_ERR_INVALID, "pt_get_stats: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = fold_timers(c);
+    if (rc != PT_OK) return rc;
+    pt::IterState h;
+    HIP_TRY(hipMemcpy(&h, c->d_state, sizeof h, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->iterations = h.iterations;
+    for (int b = 0; b < PT_MAX_DEPTH; ++b) { out->live_in[b] = h.live_in[b]; out->ray_bounces += h.live_in[b]; }
+    out->gpu_ms = c->gpu_ms;
+    out->bounce_launches = c->bounce_launches;
+    return PT_OK;
+}
+
+int pt_reset_stats(pt_ctx *c)
+{
+    if (!c) return fail(PT_ERR_INVALID, "pt_reset_stats: NULL context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = fold_timers(c);
+    if (rc != PT_OK) return rc;
+    HIP_TRY(hipMemset(c->d_state, 0, sizeof(pt::IterState)));
+    c->gpu_ms = 0.0;
+    c->bounce_launches = 0;
+    return PT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,226 @@
+// pt_device.h -- device-side math of the path tracer (gfx950 only).
+//
+// Every function here is the MI355X implementation of one function on the reference's hot path
+// (ref = /root/reference): intersections.h, interactions.h and the device functions of
+// raytraceKernel.cu.  Arithmetic is fp32, one rounding per operation (this file must be compiled with
+// -ffp-contract=off and without fast-math): results are required to equal the CPU oracle's bit for bit,
+// because a path tracer amplifies a 1-ulp difference into a different hit/miss decision.
+// hipcc's fp32 '/' and sqrtf are correctly rounded by default (-fhip-fp32-correctly-rounded-divide-sqrt).
+//
+// Primitive records are wave-uniform: all 64 lanes test the same primitive at the same time, so the
+// matrices are read once per wave (scalar loads into SGPRs, or one LDS broadcast read) and only the ray is
+// per-lane data.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptd {
+
+struct f3 { float x, y, z; };
+
+__device__ __forceinline__ f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator*(float s, f3 v) { return mk(s * v.x, s * v.y, s * v.z); }
+__device__ __forceinline__ f3 operator-(f3 a) { return mk(-a.x, -a.y, -a.z); }
+// GLM 0.9.5.4 semantics (ref: external/include/glm/detail/func_geometric.inl:66-73,108-115,215-227,256-265)
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 x, f3 y)
+{
+    return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
+}
+__device__ __forceinline__ float length(f3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
+__device__ __forceinline__ f3 normalize(f3 v)
+{
+    float inv = 1.0f / sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    return mk(v.x * inv, v.y * inv, v.z * inv);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Primitive record as the kernels see it: 32 dwords = 128 B, so one primitive is two s_load_dwordx16
+// (or two LDS broadcast b128 x4 groups).  translation/rotation/scale of staticGeom are dropped (no
+// intersection function reads them, ref: src/intersections.h:81-117).
+// ---------------------------------------------------------------------------------------------
+struct Prim {
+    uint32_t type;       // 0 sphere, 1 cube, 2 mesh (never hit)
+    uint32_t material;
+    uint32_t pad0, pad1;
+    float inv[12];       // inverseTransform rows x,y,z (x y z w each)
+    float fwd[12];       // transform rows x,y,z
+    float cx, cy, cz;    // transform * (0,0,0,1), evaluated on the host with multiplyMV's operation order
+    uint32_t pad2;
+};
+static_assert(sizeof(Prim) == 128, "Prim must be 128 B");
+
+// Material planes (SoA): plane k of material id at mats[k * nM + id]
+enum { M_CR = 0, M_CG, M_CB, M_SR, M_SG, M_SB, M_REFL, M_REFR, M_IOR, M_EMIT, M_PLANES };
+
+// ---------------------------------------------------------------------------------------------
+// RNG: Wang hash (ref: src/intersections.h:26-34) + thrust::minstd_rand + uniform_real_distribution<float>
+// (call sites ref: src/raytraceKernel.cu:32-35).  Integer-exact, so streams are identical to the oracle's.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t wang_hash(uint32_t a)
+{
+    a = (a + 0x7ed55d16u) + (a << 12);
+    a = (a ^ 0xc761c23cu) ^ (a >> 19);
+    a = (a + 0x165667b1u) + (a << 5);
+    a = (a + 0xd3a2646cu) ^ (a << 9);
+    a = (a + 0xfd7046c5u) + (a << 3);
+    a = (a ^ 0xb55a4f09u) ^ (a >> 16);
+    return a;
+}
+// wave-uniform part of the stream key: hash(iteration ^ hash(key + seed*golden))
+__host__ __device__ __forceinline__ uint32_t stream_key(uint32_t iteration, uint32_t key, uint32_t seed)
+{
+    return wang_hash(iteration ^ wang_hash(key + seed * 2654435769u));
+}
+__device__ __forceinline__ uint32_t minstd_seed(uint32_t s)
+{
+    const uint32_t m = 2147483647u;            // s % m for s < 2^32 needs at most two subtractions
+    if (s >= m) s -= m;
+    if (s >= m) s -= m;
+    return s == 0u ? 1u : s;
+}
+__device__ __forceinline__ uint32_t minstd_next(uint32_t x)
+{
+    const uint32_t m = 2147483647u;            // 48271*x mod (2^31-1) by Mersenne folding == Schrage's result
+    uint64_t p = (uint64_t)x * 48271u;
+    uint32_t r = (uint32_t)(p & m) + (uint32_t)(p >> 31);
+    return r >= m ? r - m : r;
+}
+__device__ __forceinline__ float u01_of(uint32_t x) { return (float)(x - 1u) / 2147483648.0f; }
+
+// ---------------------------------------------------------------------------------------------
+// deterministic sincos on [0, 2pi] (same polynomial, same operation order as the oracle's o_sincos_poly)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sincos_poly(float a, float &sn, float &cs)
+{
+    int k = (int)(a * 0.636619772f + 0.5f);
+    float fk = (float)k;
+    float r = ((a - fk * 1.5703125f) - fk * 4.837512969970703125e-4f) - fk * 7.54978995489188216e-8f;
+    float z = r * r;
+    float s = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    float c = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z
+              - 0.5f * z + 1.0f;
+    int q = k & 3;
+    sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
+    cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+}
+
+// multiplyMV (ref: src/intersections.h:53-59): rows 0..2 of a row-major 3x4 block dotted with (v, w)
+__device__ __forceinline__ f3 mulMV(const float *m, f3 v, float w)
+{
+    f3 r;
+    r.x = (m[0] * v.x) + (m[1] * v.y) + (m[2] * v.z) + (m[3] * w);
+    r.y = (m[4] * v.x) + (m[5] * v.y) + (m[6] * v.z) + (m[7] * w);
+    r.z = (m[8] * v.x) + (m[9] * v.y) + (m[10] * v.z) + (m[11] * w);
+    return r;
+}
+
+// getPointOnRay (ref: src/intersections.h:46-48)
+__device__ __forceinline__ f3 pointOnRay(f3 o, f3 d, float t) { return o + (t - .0001f) * normalize(d); }
+
+// ---------------------------------------------------------------------------------------------
+// One primitive against one ray.  Returns the world-space distance or -1; on a hit fills point/normal.
+// sphere: ref src/intersections.h:81-117 (bit-faithful, including the double-precision radicand);
+// cube:   the reference's stub (src/intersections.h:72-77) defined as a slab test in object space
+//         (DESIGN.md "Canonical semantics", box).
+// `g` is wave-uniform; the type branch is a scalar branch.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float intersectPrim(const Prim &g, f3 o, f3 d, f3 &point, f3 &normal)
+{
+    if (g.type > 1u) return -1.0f;                       // MESH: parsed by the loader, never has geometry
+    f3 ro = mulMV(g.inv, o, 1.0f);
+    f3 rd = normalize(mulMV(g.inv, d, 0.0f));
+    float t;
+    f3 nobj;
+    if (g.type == 0u) {
+        float vDot = dot(ro, rd);
+        float radicand = (float)((double)(vDot * vDot) - ((double)dot(ro, ro) - 0.25));
+        if (radicand < 0) return -1.0f;
+        float squareRoot = sqrtf(radicand);
+        float firstTerm = -vDot;
+        float t1 = firstTerm + squareRoot;
+        float t2 = firstTerm - squareRoot;
+        if (t1 < 0 && t2 < 0) return -1.0f;
+        else if (t1 > 0 && t2 > 0) t = (t2 < t1) ? t2 : t1;
+        else t = (t1 < t2) ? t2 : t1;
+        nobj = mk(0, 0, 0);
+    } else {
+        float inv, t0, t1, tn, tf;
+        inv = 1.0f / rd.x; t0 = (-0.5f - ro.x) * inv; t1 = (0.5f - ro.x) * inv;
+        float tmin = (t0 < t1) ? t0 : t1, tmax = (t0 < t1) ? t1 : t0;
+        int amin = 0, amax = 0;
+        inv = 1.0f / rd.y; t0 = (-0.5f - ro.y) * inv; t1 = (0.5f - ro.y) * inv;
+        tn = (t0 < t1) ? t0 : t1; tf = (t0 < t1) ? t1 : t0;
+        if (tn > tmin) { tmin = tn; amin = 1; }
+        if (tf < tmax) { tmax = tf; amax = 1; }
+        inv = 1.0f / rd.z; t0 = (-0.5f - ro.z) * inv; t1 = (0.5f - ro.z) * inv;
+        tn = (t0 < t1) ? t0 : t1; tf = (t0 < t1) ? t1 : t0;
+        if (tn > tmin) { tmin = tn; amin = 2; }
+        if (tf < tmax) { tmax = tf; amax = 2; }
+        if (tmax < tmin || tmax < 0) return -1.0f;
+        bool entry = tmin > 0;
+        t = entry ? tmin : tmax;
+        int axis = entry ? amin : amax;
+        float da = (axis == 0) ? rd.x : (axis == 1) ? rd.y : rd.z;
+        float sgn = entry ? ((da > 0) ? -1.0f : 1.0f) : ((da > 0) ? 1.0f : -1.0f);
+        nobj = mk(axis == 0 ? sgn : 0.0f, axis == 1 ? sgn : 0.0f, axis == 2 ? sgn : 0.0f);
+    }
+    f3 real = mulMV(g.fwd, pointOnRay(ro, rd, t), 1.0f);
+    point = real;
+    if (g.type == 0u) normal = normalize(real - mk(g.cx, g.cy, g.cz));
+    else normal = normalize(mulMV(g.fwd, nobj, 0.0f));
+    return length(o - real);
+}
+
+// calculateRandomDirectionInHemisphere (ref: src/interactions.h:62-87), deterministic trig
+__device__ __forceinline__ f3 randomDirectionInHemisphere(f3 normal, float xi1, float xi2)
+{
+    float up = sqrtf(xi1);
+    float over = sqrtf(1 - up * up);
+    float around = (float)((double)xi2 * 6.2831853071795864769252867665590057683943);
+    f3 notNormal;
+    if ((double)fabsf(normal.x) < 0.5773502691896257645091487805019574556476) notNormal = mk(1, 0, 0);
+    else if ((double)fabsf(normal.y) < 0.5773502691896257645091487805019574556476) notNormal = mk(0, 1, 0);
+    else notNormal = mk(0, 0, 1);
+    f3 p1 = normalize(cross(normal, notNormal));
+    f3 p2 = normalize(cross(normal, p1));
+    float sn, cs;
+    sincos_poly(around, sn, cs);
+    return ((up * normal) + ((cs * over) * p1)) + ((sn * over) * p2);
+}
+
+// calculateReflectionDirection (stub ref: src/interactions.h:47-50)
+__device__ __forceinline__ f3 reflectionDirection(f3 normal, f3 incident)
+{
+    float k = 2.0f * dot(incident, normal);
+    return incident - k * normal;
+}
+
+// calculateTransmissionDirection (stub ref: src/interactions.h:42-44); tir = total internal reflection
+__device__ __forceinline__ f3 transmissionDirection(f3 normal, f3 incident, float n1, float n2, bool &tir)
+{
+    float eta = n1 / n2;
+    float cosi = -dot(normal, incident);
+    float sin2t = (eta * eta) * (1.0f - cosi * cosi);
+    tir = sin2t > 1.0f;
+    if (tir) return mk(0, 0, 0);
+    float cost = sqrtf(1.0f - sin2t);
+    float k = eta * cosi - cost;
+    return (eta * incident) + (k * normal);
+}
+
+// calculateFresnel (stub ref: src/interactions.h:53-59): reflection coefficient of an unpolarised dielectric
+__device__ __forceinline__ float fresnelReflectance(f3 normal, f3 incident, float n1, float n2, f3 trans)
+{
+    if (trans.x == 0.0f && trans.y == 0.0f && trans.z == 0.0f) return 1.0f;
+    float cosi = -dot(normal, incident);
+    float cost = -dot(normal, trans);
+    float rs = (n1 * cosi - n2 * cost) / (n1 * cosi + n2 * cost);
+    float rp = (n2 * cosi - n1 * cost) / (n2 * cosi + n1 * cost);
+    return 0.5f * (rs * rs + rp * rp);
+}
+
+}  // namespace ptd

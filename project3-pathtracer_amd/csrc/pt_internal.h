@@ -1,0 +1,67 @@
+// pt_internal.h -- shared between the C-ABI host code (pt_context.hip) and the kernels (pt_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pt_abi.h"
+#include "pt_device.h"
+
+namespace pt {
+
+// Ray pool, SoA of 16-byte lanes: one ray = 40 B = a(16) + b(16) + c(8).  A wave's 64 consecutive rays are
+// read/written with two global_load/store_dwordx4 and one dwordx2 per lane, fully coalesced.
+//   a = (origin.x, origin.y, origin.z, direction.x)
+//   b = (direction.y, direction.z, throughput.r, throughput.g)
+//   c = (throughput.b, bit pattern of the tile-local pixel index)
+struct RayPool {
+    float4 *a;
+    float4 *b;
+    float2 *c;
+};
+
+// Device-resident per-render state.  The iteration counter lives here (not in a kernel argument) so that
+// one captured hipGraph can be replayed for every iteration.
+struct IterState {
+    uint32_t iter;                               // iteration being rendered (1-based, ref: src/main.cpp:95)
+    uint32_t pad[3];
+    uint32_t counts[PT_MAX_DEPTH + 1];           // live rays entering bounce b of this iteration
+    unsigned long long live_in[PT_MAX_DEPTH];    // the same, summed over iterations (stats)
+    unsigned long long iterations;
+};
+
+struct KParams {
+    // camera basis (host-side part of raycastFromCameraKernel)
+    float eye[3], M[3], H[3], V[3];
+    float resx, resy;
+    int W;                 // frame width
+    int row_begin;         // first frame row of this context's tile
+    int npix;              // pixels in the tile
+    uint32_t pix_offset;   // global pixel index of tile-local pixel 0 (= row_begin * W)
+    int nG, nM;
+    int depth;
+    int rr_start;
+    uint32_t seed;
+    const ptd::Prim *prims;
+    const float *mats;     // M_PLANES planes of nM floats
+    float *image;          // tile framebuffer, fp32 RGB packed (12 B/pixel)
+    IterState *st;
+    RayPool pool[2];
+};
+
+struct LaunchCfg {
+    int workgroup;   // 64..1024
+    int grid;        // workgroups per bounce launch
+    bool geom_lds;
+    bool compact;
+};
+
+// kernels (pt_kernels.hip)
+hipError_t launch_iter_set(hipStream_t s, IterState *st, uint32_t value);
+hipError_t launch_iter_begin(hipStream_t s, IterState *st, int npix, int depth, bool compact);
+hipError_t launch_iter_fold(hipStream_t s, IterState *st, int depth);
+hipError_t launch_bounce(hipStream_t s, const KParams &p, const LaunchCfg &cfg, int bounce);
+hipError_t launch_send_image_to_pbo(hipStream_t s, pt_uchar4 *pbo, const float *image, int npix);
+size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg);
+int bounce_max_blocks_per_cu(const KParams &p, const LaunchCfg &cfg);
+
+}  // namespace pt

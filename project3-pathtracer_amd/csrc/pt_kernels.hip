@@ -1,0 +1,404 @@
+// pt_kernels.hip -- hand-written HIP kernels of the path-tracing hot path for gfx950 (MI355X, CDNA4).
+//
+//   k_bounce<FIRST=true>   raycastFromCameraKernel fused into bounce 0      (ref stub: src/raytraceKernel.cu:38-45)
+//   k_bounce               one bounce of raytraceRay: nearest hit over the primitive list, shading,
+//                          Russian roulette, framebuffer accumulate            (ref stub: src/raytraceKernel.cu:91-104)
+//                          + stream compaction of the surviving rays           (ref: README.md:70, absent in the code)
+//   k_send_image_to_pbo    sendImageToPBO                                      (ref: src/raytraceKernel.cu:58-89)
+//   k_iter_*               iteration bookkeeping (live-ray counters, stats) kept on the device so that one
+//                          hipGraph can be replayed per iteration
+//
+// Execution model (wave64): one lane = one live ray; the primitive loop is wave-uniform, so primitive
+// records travel through the scalar unit (s_load -> SGPR operands of the VALU ops) or one LDS broadcast read.
+// Rays live in SoA pools (pt_internal.h RayPool); survivors of a bounce are written densely into the other
+// pool: wave ballot + v_mbcnt prefix, an LDS scan over the workgroup's waves, one global atomic per
+// workgroup.  Results do not depend on the order rays land in the pool because every RNG stream is keyed on
+// (global pixel, iteration, bounce).
+//
+// Compile with -ffp-contract=off (see pt_device.h).
+#include "pt_internal.h"
+
+namespace pt {
+using namespace ptd;
+
+static constexpr uint32_t DEAD = 0xFFFFFFFFu;
+
+typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
+
+// Wave-uniform primitive fetch through the constant address space: hipcc turns this into s_load_dwordx16 x2
+// and keeps the record in SGPRs.
+__device__ __forceinline__ Prim load_prim_scalar(const Prim *prims, int g)
+{
+    Prim r;
+    const_u32_ptr q = (const_u32_ptr)(uintptr_t)(prims + g);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) dst[k] = q[k];
+    return r;
+}
+
+struct Hit {
+    f3 p, n;
+    uint32_t material;
+    bool any;
+};
+
+template <bool GEOM_LDS>
+__device__ __forceinline__ Hit nearestHit(const KParams &p, const Prim *s_prims, f3 o, f3 d)
+{
+    Hit h;
+    h.any = false;
+    h.material = 0;
+    h.p = mk(0, 0, 0);
+    h.n = mk(0, 0, 0);
+    float best_t = 0.0f;
+    for (int g = 0; g < p.nG; ++g) {
+        f3 ip, in;
+        float t;
+        uint32_t mat;
+        if (GEOM_LDS) {
+            const Prim &P = s_prims[g];
+            t = intersectPrim(P, o, d, ip, in);
+            mat = P.material;
+        } else {
+            const Prim P = load_prim_scalar(p.prims, g);
+            t = intersectPrim(P, o, d, ip, in);
+            mat = P.material;
+        }
+        if (t > 0 && (!h.any || t < best_t)) {      // smallest t > 0, ties keep the lowest index
+            h.any = true;
+            best_t = t;
+            h.p = ip;
+            h.n = in;
+            h.material = mat;
+        }
+    }
+    return h;
+}
+
+template <int WG, bool FIRST, bool GEOM_LDS, bool COMPACT>
+__global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce)
+{
+    constexpr int NW = WG / 64;
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+    // LDS carve: [prims nG*128 B (GEOM_LDS only)] [material planes nM*M_PLANES f32] [scan scratch]
+    Prim *s_prims = reinterpret_cast<Prim *>(smem);
+    const int prim_bytes = GEOM_LDS ? p.nG * (int)sizeof(Prim) : 0;
+    float *s_mats = reinterpret_cast<float *>(smem + prim_bytes);
+    const int mat_words = (p.nM * M_PLANES + 3) & ~3;
+    uint32_t *s_scan = reinterpret_cast<uint32_t *>(s_mats + mat_words);   // [2][NW] wave totals, [2] bases
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    if (GEOM_LDS) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.prims);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_prims);
+        for (int k = tid; k < p.nG * 8; k += WG) dst[k] = src[k];
+    }
+    for (int k = tid; k < p.nM * M_PLANES; k += WG) s_mats[k] = p.mats[k];
+    __syncthreads();
+
+    IterState *st = p.st;
+    const uint32_t iter = st->iter;
+    const uint32_t n = (FIRST || !COMPACT) ? (uint32_t)p.npix : st->counts[bounce];
+    const RayPool in = p.pool[bounce & 1];
+    const RayPool out = p.pool[(bounce + 1) & 1];
+    const bool last = (bounce == p.depth - 1);
+    const uint32_t key_cam = stream_key(iter, 0u, p.seed);
+    const uint32_t key_bounce = stream_key(iter, (uint32_t)bounce + 1u, p.seed);
+    const float fi = (float)iter, fim1 = (float)(iter - 1u);
+
+    uint32_t live_count = 0;      // !COMPACT: rays this wave found alive on entry
+    int round = 0;
+    for (uint32_t base = blockIdx.x * WG; base < n; base += gridDim.x * WG, ++round) {
+        const uint32_t i = base + tid;
+        bool valid = i < n;
+        f3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(1, 1, 1);
+        uint32_t pix = 0;
+        if (FIRST) {
+            if (valid) {
+                // raycastFromCameraKernel: jittered pinhole ray through tile-local pixel i
+                pix = i;
+                const uint32_t gp = pix + p.pix_offset;
+                const uint32_t x = i % (uint32_t)p.W;
+                const uint32_t y = (uint32_t)p.row_begin + i / (uint32_t)p.W;
+                uint32_t s = minstd_seed(wang_hash(gp ^ key_cam));
+                s = minstd_next(s);
+                const float jx = u01_of(s);
+                s = minstd_next(s);
+                const float jy = u01_of(s);
+                const float sx = ((float)x + jx) / p.resx;
+                const float sy = ((float)y + jy) / p.resy;
+                const f3 eye = mk(p.eye[0], p.eye[1], p.eye[2]);
+                const f3 P = (mk(p.M[0], p.M[1], p.M[2]) + (1.0f - 2.0f * sx) * mk(p.H[0], p.H[1], p.H[2])) +
+                             (1.0f - 2.0f * sy) * mk(p.V[0], p.V[1], p.V[2]);
+                o = eye;
+                d = normalize(P - eye);
+            }
+        } else {
+            if (valid) {
+                const float2 c = in.c[i];
+                pix = __float_as_uint(c.y);
+                if (!COMPACT && pix == DEAD) valid = false;
+                if (valid) {
+                    const float4 a = in.a[i];
+                    const float4 b = in.b[i];
+                    o = mk(a.x, a.y, a.z);
+                    d = mk(a.w, b.x, b.y);
+                    T = mk(b.z, b.w, c.x);
+                }
+            }
+        }
+        if (!COMPACT) live_count += (uint32_t)__popcll(__ballot(valid));
+
+        bool alive = false;
+        if (valid) {
+            f3 L = mk(0, 0, 0);
+            const Hit h = nearestHit<GEOM_LDS>(p, s_prims, o, d);
+            if (h.any) {
+                const uint32_t m = h.material;
+                const float emit = s_mats[M_EMIT * p.nM + m];
+                if (emit > 0.0f) {
+                    const f3 col = mk(s_mats[M_CR * p.nM + m], s_mats[M_CG * p.nM + m], s_mats[M_CB * p.nM + m]);
+                    L = emit * (T * col);
+                } else if (!last) {
+                    // calculateBSDF: pick the lobe, build the next ray
+                    uint32_t s = minstd_seed(wang_hash((pix + p.pix_offset) ^ key_bounce));
+                    s = minstd_next(s);
+                    const float u_select = u01_of(s);
+                    s = minstd_next(s);
+                    const float xi1 = u01_of(s);
+                    s = minstd_next(s);
+                    const float xi2 = u01_of(s);
+                    s = minstd_next(s);
+                    const float u_rr = u01_of(s);
+
+                    const float ndotd = dot(h.n, d);
+                    const bool backside = ndotd > 0.0f;
+                    const f3 nf = backside ? -h.n : h.n;
+                    const float refr = s_mats[M_REFR * p.nM + m];
+                    const float refl = s_mats[M_REFL * p.nM + m];
+                    f3 nd;
+                    f3 bias_n = nf;
+                    if (refr > 0.0f) {
+                        const float ior = s_mats[M_IOR * p.nM + m];
+                        const float n1 = backside ? ior : 1.0f;
+                        const float n2 = backside ? 1.0f : ior;
+                        const f3 rdir = reflectionDirection(nf, d);
+                        bool tir;
+                        const f3 tdir = transmissionDirection(nf, d, n1, n2, tir);
+                        const float R = fresnelReflectance(nf, d, n1, n2, tdir);
+                        T = T * mk(s_mats[M_SR * p.nM + m], s_mats[M_SG * p.nM + m], s_mats[M_SB * p.nM + m]);
+                        if (u_select < R) nd = rdir;
+                        else { nd = tdir; bias_n = -nf; }
+                    } else if (refl > 0.0f) {
+                        T = T * mk(s_mats[M_SR * p.nM + m], s_mats[M_SG * p.nM + m], s_mats[M_SB * p.nM + m]);
+                        nd = reflectionDirection(nf, d);
+                    } else {
+                        T = T * mk(s_mats[M_CR * p.nM + m], s_mats[M_CG * p.nM + m], s_mats[M_CB * p.nM + m]);
+                        nd = randomDirectionInHemisphere(nf, xi1, xi2);
+                    }
+                    o = h.p + 0.0002f * bias_n;       // RAY_BIAS_AMOUNT, ref: src/utilities.h:26
+                    d = nd;
+                    alive = true;
+                    if (p.rr_start >= 0 && bounce >= p.rr_start) {      // Russian roulette
+                        float q = T.x;
+                        if (T.y > q) q = T.y;
+                        if (T.z > q) q = T.z;
+                        q = (q < 0.05f) ? 0.05f : ((q > 1.0f) ? 1.0f : q);
+                        if (u_rr >= q) alive = false;
+                        else T = mk(T.x / q, T.y / q, T.z / q);
+                    }
+                }
+            }
+            if (!alive) {
+                // the path ends here: its single read-modify-write of the pixel's running mean
+                float *px = p.image + 3u * (size_t)pix;
+                const float r0 = px[0], r1 = px[1], r2 = px[2];
+                px[0] = (r0 * fim1 + L.x) / fi;
+                px[1] = (r1 * fim1 + L.y) / fi;
+                px[2] = (r2 * fim1 + L.z) / fi;
+            }
+        }
+
+        if (last) continue;      // wave-uniform: nothing survives the last bounce
+
+        if (COMPACT) {
+            // stream compaction: wave ballot/mbcnt prefix -> LDS scan over waves -> one atomic per workgroup
+            const uint64_t mask = __ballot(alive);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            const uint32_t wtot = (uint32_t)__popcll(mask);
+            uint32_t dst;
+            if (NW == 1) {
+                uint32_t b = 0;
+                if (lane == 0 && wtot) b = atomicAdd(&st->counts[bounce + 1], wtot);
+                dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)b) + rank;
+            } else {
+                const int par = round & 1;
+                uint32_t *tot = s_scan + par * NW;
+                uint32_t *gbase = s_scan + 2 * NW + par;
+                if (lane == 0) tot[wave] = wtot;
+                __syncthreads();
+                if (tid == 0) {
+                    uint32_t sum = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) sum += tot[w];
+                    *gbase = sum ? atomicAdd(&st->counts[bounce + 1], sum) : 0u;
+                }
+                __syncthreads();
+                uint32_t off = *gbase;
+                for (int w = 0; w < wave; ++w) off += tot[w];
+                dst = off + rank;
+            }
+            if (alive) {
+                out.a[dst] = make_float4(o.x, o.y, o.z, d.x);
+                out.b[dst] = make_float4(d.y, d.z, T.x, T.y);
+                out.c[dst] = make_float2(T.z, __uint_as_float(pix));
+            }
+        } else {
+            // no compaction (validation / ablation mode): the ray keeps slot i, dead slots are tagged
+            if (i < n) {
+                if (alive) {
+                    out.a[i] = make_float4(o.x, o.y, o.z, d.x);
+                    out.b[i] = make_float4(d.y, d.z, T.x, T.y);
+                    out.c[i] = make_float2(T.z, __uint_as_float(pix));
+                } else {
+                    out.c[i] = make_float2(0.0f, __uint_as_float(DEAD));
+                }
+            }
+        }
+    }
+    if (!COMPACT) {
+        if (lane == 0 && live_count) atomicAdd(&st->counts[bounce], live_count);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// iteration bookkeeping
+// ---------------------------------------------------------------------------------------------
+__global__ void k_iter_set(IterState *st, uint32_t value) { st->iter = value; }
+
+// fold the previous iteration's per-bounce live counts into the stats, reset them, advance the iteration
+__global__ void k_iter_begin(IterState *st, uint32_t npix, int depth, int compact)
+{
+    const int b = threadIdx.x;
+    if (b < depth) st->live_in[b] += st->counts[b];
+    __syncthreads();
+    if (b <= depth) st->counts[b] = (b == 0 && compact) ? npix : 0u;
+    if (b == 0) { st->iter += 1u; st->iterations += 1ull; }
+}
+
+__global__ void k_iter_fold(IterState *st, int depth)
+{
+    const int b = threadIdx.x;
+    if (b < depth) st->live_in[b] += st->counts[b];
+    __syncthreads();
+    if (b <= depth) st->counts[b] = 0u;
+}
+
+// sendImageToPBO (ref: src/raytraceKernel.cu:58-89): x255 (the reference multiplies by the double 255.0 and
+// stores to float: one rounding, identical to the fp32 product), clamp above, truncate, w = 0.
+__global__ __launch_bounds__(256) void k_send_image_to_pbo(pt_uchar4 *pbo, const float *image, int npix)
+{
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+        float r = image[3 * i] * 255.0f, g = image[3 * i + 1] * 255.0f, b = image[3 * i + 2] * 255.0f;
+        if (r > 255) r = 255;
+        if (g > 255) g = 255;
+        if (b > 255) b = 255;
+        pt_uchar4 o;
+        o.x = (unsigned char)r;
+        o.y = (unsigned char)g;
+        o.z = (unsigned char)b;
+        o.w = 0;
+        pbo[i] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg)
+{
+    size_t prim = cfg.geom_lds ? (size_t)p.nG * sizeof(Prim) : 0;
+    size_t mats = (size_t)((p.nM * M_PLANES + 3) & ~3) * sizeof(float);
+    size_t scan = (size_t)(2 * (cfg.workgroup / 64) + 2) * sizeof(uint32_t);
+    return prim + mats + scan;
+}
+
+template <int WG, bool GEOM_LDS, bool COMPACT>
+static const void *bounce_fn(bool first)
+{
+    return first ? (const void *)k_bounce<WG, true, GEOM_LDS, COMPACT> : (const void *)k_bounce<WG, false, GEOM_LDS, COMPACT>;
+}
+
+template <int WG>
+static const void *bounce_fn_wg(bool first, bool geom_lds, bool compact)
+{
+    if (geom_lds) return compact ? bounce_fn<WG, true, true>(first) : bounce_fn<WG, true, false>(first);
+    return compact ? bounce_fn<WG, false, true>(first) : bounce_fn<WG, false, false>(first);
+}
+
+static const void *select_bounce(const LaunchCfg &cfg, bool first)
+{
+    switch (cfg.workgroup) {
+    case 64: return bounce_fn_wg<64>(first, cfg.geom_lds, cfg.compact);
+    case 128: return bounce_fn_wg<128>(first, cfg.geom_lds, cfg.compact);
+    case 256: return bounce_fn_wg<256>(first, cfg.geom_lds, cfg.compact);
+    case 512: return bounce_fn_wg<512>(first, cfg.geom_lds, cfg.compact);
+    case 1024: return bounce_fn_wg<1024>(first, cfg.geom_lds, cfg.compact);
+    default: return nullptr;
+    }
+}
+
+int bounce_max_blocks_per_cu(const KParams &p, const LaunchCfg &cfg)
+{
+    const void *fn = select_bounce(cfg, false);
+    int nb = 0;
+    if (!fn) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, cfg.workgroup, bounce_lds_bytes(p, cfg)) != hipSuccess)
+        return 0;
+    return nb;
+}
+
+hipError_t launch_bounce(hipStream_t s, const KParams &p, const LaunchCfg &cfg, int bounce)
+{
+    const void *fn = select_bounce(cfg, bounce == 0);
+    if (!fn) return hipErrorInvalidValue;
+    KParams pc = p;
+    int b = bounce;
+    void *args[] = {(void *)&pc, (void *)&b};
+    return hipLaunchKernel(fn, dim3((unsigned)cfg.grid), dim3((unsigned)cfg.workgroup), args,
+                           bounce_lds_bytes(p, cfg), s);
+}
+
+hipError_t launch_iter_set(hipStream_t s, IterState *st, uint32_t value)
+{
+    hipLaunchKernelGGL(k_iter_set, dim3(1), dim3(1), 0, s, st, value);
+    return hipGetLastError();
+}
+
+hipError_t launch_iter_begin(hipStream_t s, IterState *st, int npix, int depth, bool compact)
+{
+    hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(128), 0, s, st, (uint32_t)npix, depth, compact ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_iter_fold(hipStream_t s, IterState *st, int depth)
+{
+    hipLaunchKernelGGL(k_iter_fold, dim3(1), dim3(128), 0, s, st, depth);
+    return hipGetLastError();
+}
+
+hipError_t launch_send_image_to_pbo(hipStream_t s, pt_uchar4 *pbo, const float *image, int npix)
+{
+    int grid = (npix + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_send_image_to_pbo, dim3(grid), dim3(256), 0, s, pbo, image, npix);
+    return hipGetLastError();
+}
+
+}  // namespace pt

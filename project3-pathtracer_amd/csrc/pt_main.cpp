@@ -1,0 +1,172 @@
+// pt_main.cpp -- headless driver: the reference application's protocol around the renderer, without the
+// GL window (ref: src/main.cpp).  Same argument syntax (`scene=<file> frame=<n>`, :25-36), same call sequence
+// into cudaRaytraceCore (one call per iteration with iterations pre-incremented 1..N, fresh geom/material
+// copies per call, :93-113), same end-of-render image write-out (x flip, "<name>.<frame>.bmp", :116-141) and
+// frame sequencing (:147-157).  The PBO argument is NULL: there is no GL context on a compute node.
+//
+// Extra key=value arguments (the reference has none of them):
+//   rotat=radians|degrees   ROTAT unit (default radians = what the reference binary does)
+//   res=WxH                 RES override, fov.x recomputed as the loader does
+//   iterations=N            ITERATIONS override
+//   out=<dir>               directory for the image file (default: current directory)
+// Trace depth, Russian roulette, seed: environment, see pt_shim.cpp.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "pt_refstructs.h"
+#include "pt_scene.h"
+
+using namespace std;
+
+namespace {
+
+ptamd::scene *renderScene = nullptr;
+camera renderCamStorage;
+camera *renderCam = nullptr;
+int targetFrame = 0, iterations = 0;
+bool singleFrameMode = false, finishedRender = false;
+string outDir;
+
+// the reference's scene object owns glm arrays; this builds the same views over ptamd::scene's vectors
+vector<geom> refGeoms;
+vector<material> refMaterials;
+
+void bindScene()
+{
+    static_assert(sizeof(glm::vec3) == sizeof(pt_vec3) && sizeof(cudaMat4) == sizeof(pt_mat4), "layouts");
+    refGeoms.resize(renderScene->objects.size());
+    for (size_t i = 0; i < refGeoms.size(); i++) {
+        ptamd::geom &o = renderScene->objects[i];
+        geom &g = refGeoms[i];
+        g.type = (GEOMTYPE)o.type;
+        g.materialid = o.materialid;
+        g.frames = o.frames;
+        g.translations = reinterpret_cast<glm::vec3 *>(o.translations.data());
+        g.rotations = reinterpret_cast<glm::vec3 *>(o.rotations.data());
+        g.scales = reinterpret_cast<glm::vec3 *>(o.scales.data());
+        g.transforms = reinterpret_cast<cudaMat4 *>(o.transforms.data());
+        g.inverseTransforms = reinterpret_cast<cudaMat4 *>(o.inverseTransforms.data());
+    }
+    refMaterials.resize(renderScene->materials.size());
+    if (!refMaterials.empty())
+        memcpy(refMaterials.data(), renderScene->materials.data(), refMaterials.size() * sizeof(material));
+    ptamd::camera &c = renderScene->renderCam;
+    renderCamStorage.resolution = {c.resolution.x, c.resolution.y};
+    renderCamStorage.positions = reinterpret_cast<glm::vec3 *>(c.positions.data());
+    renderCamStorage.views = reinterpret_cast<glm::vec3 *>(c.views.data());
+    renderCamStorage.ups = reinterpret_cast<glm::vec3 *>(c.ups.data());
+    renderCamStorage.frames = c.frames;
+    renderCamStorage.fov = {c.fov.x, c.fov.y};
+    renderCamStorage.iterations = c.iterations;
+    renderCamStorage.image = reinterpret_cast<glm::vec3 *>(c.image.data());
+    renderCamStorage.rayList = nullptr;
+    renderCamStorage.imageName = c.imageName;
+    renderCam = &renderCamStorage;
+}
+
+bool replaceString(string &str, const string &from, const string &to)
+{
+    size_t pos = str.find(from);
+    if (pos == string::npos) return false;
+    str.replace(pos, from.length(), to);
+    return true;
+}
+
+// one pass of the reference's runCuda() (ref: src/main.cpp:88-159); returns false when there is nothing left
+bool runCuda()
+{
+    if (iterations < (int)renderCam->iterations) {
+        iterations++;
+        // pack geom and material arrays: fresh copies every call, as the reference does
+        vector<geom> geoms(refGeoms);
+        vector<material> materials(refMaterials);
+        cudaRaytraceCore(nullptr, renderCam, targetFrame, iterations, materials.data(), (int)materials.size(),
+                         geoms.data(), (int)geoms.size());
+        return true;
+    }
+    if (!finishedRender) {
+        string filename = renderCam->imageName;
+        stringstream out;
+        out << targetFrame;
+        const string s = out.str();
+        replaceString(filename, ".bmp", "." + s + ".bmp");
+        replaceString(filename, ".png", "." + s + ".bmp");     // PNG output is not built: BMP is written instead
+        if (!outDir.empty()) filename = outDir + "/" + filename;
+        const int W = (int)renderCam->resolution.x, H = (int)renderCam->resolution.y;
+        if (pt_save_image_bmp(filename.c_str(), reinterpret_cast<float *>(renderCam->image), W, H, 1) != PT_OK)
+            cout << "ERROR: cannot write " << filename << endl;
+        else
+            cout << "Saved frame " << s << " to " << filename << endl;
+        finishedRender = true;
+        if (singleFrameMode) return false;
+    }
+    if (targetFrame < renderCam->frames - 1) {
+        targetFrame++;
+        iterations = 0;
+        for (size_t i = 0; i < renderScene->renderCam.image.size(); i++) renderCam->image[i] = {0, 0, 0};
+        finishedRender = false;
+        return true;
+    }
+    return false;
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    bool loadedScene = false;
+    string scenePath;
+    int rotat = PT_ROTAT_RADIANS, resW = 0, resH = 0, iterOverride = -1;
+    for (int i = 1; i < argc; i++) {
+        string header, data;
+        istringstream liness(argv[i]);
+        getline(liness, header, '=');
+        getline(liness, data, '=');
+        if (header == "scene") { scenePath = data; loadedScene = true; }
+        else if (header == "frame") { targetFrame = atoi(data.c_str()); singleFrameMode = true; }
+        else if (header == "rotat") rotat = (data == "degrees") ? PT_ROTAT_DEGREES : PT_ROTAT_RADIANS;
+        else if (header == "res") { if (sscanf(data.c_str(), "%dx%d", &resW, &resH) != 2) resW = resH = 0; }
+        else if (header == "iterations") iterOverride = atoi(data.c_str());
+        else if (header == "out") outDir = data;
+    }
+    if (!loadedScene) {
+        cout << "Error: scene file needed!" << endl;
+        return 0;
+    }
+    cout << "Reading scene from " << scenePath << " ..." << endl;
+    renderScene = new ptamd::scene(scenePath, rotat);
+    if (!renderScene->ok) {
+        cout << "ERROR: cannot open " << scenePath << endl;
+        return 1;
+    }
+    for (const string &e : renderScene->errors) cout << "ERROR: " << e << endl;
+    if (resW > 0 && resH > 0) {
+        ptamd::camera &c = renderScene->renderCam;
+        c.resolution = {(float)resW, (float)resH};
+        c.fov = ptamd::cameraFov(c.fov.y, c.resolution);
+        c.image.assign((size_t)resW * (size_t)resH, pt_vec3{0, 0, 0});
+    }
+    if (iterOverride >= 0) renderScene->renderCam.iterations = (unsigned)iterOverride;
+    bindScene();
+    if (targetFrame >= renderCam->frames) {
+        cout << "Warning: Specified target frame is out of range, defaulting to frame 0." << endl;
+        targetFrame = 0;
+    }
+    cout << "Loaded " << refGeoms.size() << " objects, " << refMaterials.size() << " materials, "
+         << (int)renderCam->resolution.x << "x" << (int)renderCam->resolution.y << ", " << renderCam->iterations
+         << " iterations" << endl;
+
+    const auto t0 = chrono::steady_clock::now();
+    long long calls = 0;
+    while (runCuda()) calls++;
+    const double sec = chrono::duration<double>(chrono::steady_clock::now() - t0).count();
+    cout << "Done: " << calls << " driver passes in " << sec << " s" << endl;
+    return 0;
+}

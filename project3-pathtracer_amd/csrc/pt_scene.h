@@ -1,0 +1,59 @@
+// pt_scene.h -- host-side mirror of the reference's scene interface (ref: src/scene.h:19-32,
+// src/sceneStructs.h:21-61): same class name, same public members (objects, materials, renderCam) and the
+// same per-frame array layout, built on the POD types of include/pt_abi.h instead of glm.
+#pragma once
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_abi.h"
+
+namespace ptamd {
+
+// geom, ref: src/sceneStructs.h:21-30 (per-frame arrays owned by the scene)
+struct geom {
+    int type = PT_SPHERE;
+    int materialid = 0;
+    int frames = 0;                 // the reference never initialises this field; here it is the frame count
+    std::vector<pt_vec3> translations, rotations, scales;
+    std::vector<pt_mat4> transforms, inverseTransforms;
+};
+
+// camera, ref: src/sceneStructs.h:50-61
+struct camera {
+    pt_vec2 resolution = {0, 0};
+    std::vector<pt_vec3> positions, views, ups;
+    int frames = 0;
+    pt_vec2 fov = {0, 0};
+    unsigned int iterations = 0;
+    std::vector<pt_vec3> image;     // W*H running-mean framebuffer, zero-initialised (ref: src/scene.cpp:212-216)
+    std::string imageName;
+};
+
+class scene {
+public:
+    explicit scene(const std::string &filename, int rotat_units = PT_ROTAT_RADIANS);
+    std::vector<geom> objects;
+    std::vector<pt_material> materials;
+    camera renderCam;
+    bool ok = false;                // file opened
+    std::vector<std::string> errors;
+
+private:
+    std::ifstream fp_in;
+    int rotat_units_;
+    int loadMaterial(const std::string &materialid);
+    int loadObject(const std::string &objectid);
+    int loadCamera();
+};
+
+// utilityCore::buildTransformationMatrix + glmMat4ToCudaMat4 (ref: src/utilities.cpp:74-90)
+pt_mat4 buildTransformationMatrix(pt_vec3 translation, pt_vec3 rotation, pt_vec3 scale, int rotat_units,
+                                  pt_mat4 *inverse_out);
+pt_vec2 cameraFov(float fovy, pt_vec2 resolution);   // ref: src/scene.cpp:204-207
+
+}  // namespace ptamd
+
+struct pt_scene {
+    ptamd::scene *s;
+};

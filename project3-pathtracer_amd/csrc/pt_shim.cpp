@@ -1,0 +1,126 @@
+// pt_shim.cpp -- reference-side binding: the renderer entry point with the reference's exact signature
+// (ref: src/raytraceKernel.h:17), implemented on the C-ABI of libptamd.so.
+//
+// Drop-in use: compile this file in place of src/raytraceKernel.cu, with "sceneStructs.h" from the
+// reference instead of pt_refstructs.h, and link libptamd.so.  It does what the host
+// body of the reference's function does (ref: src/raytraceKernel.cu:106-165) -- flatten geoms[i] at `frame`
+// into staticGeom records, pack cameraData, run one iteration, fill the PBO and renderCam->image -- but on
+// a persistent context: no per-call cudaMalloc/cudaFree, and the D2H copy of the image only when the caller
+// will look at it.
+//
+// Knobs the reference keeps as source constants come from the environment (read once):
+//   PT_DEPTH (8)          bounces per path (the reference's traceDepth, src/raytraceKernel.cu:110)
+//   PT_RR_START (-1)      first bounce with Russian roulette, -1 = off
+//   PT_SEED (0)           RNG stream selector
+//   PT_DEVICE (0)         HIP device
+//   PT_READBACK_EVERY (0) also copy the image back every N iterations (0 = only on the last one,
+//                         iterations == renderCam->iterations, which is when src/main.cpp:114-125 reads it);
+//                         1 reproduces the reference's copy on every call
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/pt_abi.h"
+#include "pt_refstructs.h"
+
+namespace {
+
+struct ShimState {
+    pt_ctx *ctx = nullptr;
+    std::vector<pt_static_geom> geoms;
+    std::vector<pt_material> mats;
+    pt_camera_data cam;
+    bool have_cam = false;
+    int readback_every = 0;
+    int last_iteration = 0;     // the iteration the device framebuffer currently holds the mean of
+};
+ShimState g;
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// checkCUDAError's convention (ref: src/raytraceKernel.cu:19-25): print and exit
+void check(int rc, const char *msg)
+{
+    if (rc == PT_OK) return;
+    fprintf(stderr, "Cuda error: %s: %s.\n", msg, pt_last_error());
+    exit(EXIT_FAILURE);
+}
+
+}  // namespace
+
+void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iterations, material *materials,
+                      int numberOfMaterials, geom *geoms, int numberOfGeoms)
+{
+    if (!g.ctx) {
+        check(pt_create(env_int("PT_DEVICE", 0), &g.ctx), "pt_create");
+        pt_options o;
+        pt_default_options(&o);
+        o.depth = env_int("PT_DEPTH", o.depth);
+        o.rr_start = env_int("PT_RR_START", o.rr_start);
+        o.seed = (unsigned)env_int("PT_SEED", 0);
+        check(pt_set_options(g.ctx, &o), "pt_set_options");
+        g.readback_every = env_int("PT_READBACK_EVERY", 0);
+    }
+
+    // package geometry (ref: src/raytraceKernel.cu:123-134).  geom::frames is never initialised by the
+    // reference's loader, so it is not read here either.
+    std::vector<pt_static_geom> list((size_t)numberOfGeoms);
+    for (int i = 0; i < numberOfGeoms; i++) {
+        pt_static_geom &s = list[(size_t)i];
+        memset(&s, 0, sizeof s);
+        s.type = (int)geoms[i].type;
+        s.materialid = geoms[i].materialid;
+        memcpy(&s.translation, &geoms[i].translations[frame], sizeof s.translation);
+        memcpy(&s.rotation, &geoms[i].rotations[frame], sizeof s.rotation);
+        memcpy(&s.scale, &geoms[i].scales[frame], sizeof s.scale);
+        memcpy(&s.transform, &geoms[i].transforms[frame], sizeof s.transform);
+        memcpy(&s.inverseTransform, &geoms[i].inverseTransforms[frame], sizeof s.inverseTransform);
+    }
+    std::vector<pt_material> mats((size_t)numberOfMaterials);
+    static_assert(sizeof(pt_material) == sizeof(material), "material layout");
+    if (numberOfMaterials > 0) memcpy(mats.data(), materials, (size_t)numberOfMaterials * sizeof(pt_material));
+
+    const bool scene_changed =
+        list.size() != g.geoms.size() || mats.size() != g.mats.size() ||
+        (!list.empty() && memcmp(list.data(), g.geoms.data(), list.size() * sizeof(pt_static_geom)) != 0) ||
+        (!mats.empty() && memcmp(mats.data(), g.mats.data(), mats.size() * sizeof(pt_material)) != 0);
+    if (scene_changed) {
+        check(pt_set_scene(g.ctx, list.data(), numberOfGeoms, mats.data(), numberOfMaterials), "pt_set_scene");
+        g.geoms = list;
+        g.mats = mats;
+    }
+
+    // package camera (ref: src/raytraceKernel.cu:141-146)
+    pt_camera_data cam;
+    memset(&cam, 0, sizeof cam);
+    cam.resolution = {renderCam->resolution.x, renderCam->resolution.y};
+    memcpy(&cam.position, &renderCam->positions[frame], sizeof cam.position);
+    memcpy(&cam.view, &renderCam->views[frame], sizeof cam.view);
+    memcpy(&cam.up, &renderCam->ups[frame], sizeof cam.up);
+    cam.fov = {renderCam->fov.x, renderCam->fov.y};
+    if (!g.have_cam || memcmp(&cam, &g.cam, sizeof cam) != 0) {
+        check(pt_set_camera(g.ctx, &cam), "pt_set_camera");
+        g.cam = cam;
+        g.have_cam = true;
+    }
+
+    // one iteration.  iterations == 1 restarts the running mean (the old image is multiplied by 0); a later
+    // iteration on a context without history first takes the caller's image (ref: src/raytraceKernel.cu:120).
+    float *host_image = reinterpret_cast<float *>(renderCam->image);
+    const bool last = (unsigned)iterations >= renderCam->iterations;
+    const bool readback = host_image && (last || (g.readback_every > 0 && iterations % g.readback_every == 0));
+    if (iterations > 1 && iterations != g.last_iteration + 1 && host_image)
+        check(pt_upload_image(g.ctx, host_image), "pt_upload_image");
+    check(pt_render(g.ctx, iterations, 1), "pt_render");
+    if (PBOpos) check(pt_send_image_to_pbo(g.ctx, reinterpret_cast<pt_uchar4 *>(PBOpos)), "pt_send_image_to_pbo");
+    if (readback) check(pt_download_image(g.ctx, host_image), "pt_download_image");
+    // make certain the kernels have completed (ref: src/raytraceKernel.cu:162-164)
+    check(pt_synchronize(g.ctx), "Kernel failed!");
+    g.last_iteration = iterations;
+}

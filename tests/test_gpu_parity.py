@@ -1,0 +1,317 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the CPU oracle.
+
+Bar (BASELINE.json north_star): float RGB within 1e-4 of the CPU re-execution at a fixed seed.  Because both
+sides evaluate the same fp32 operations with one rounding each, the images are expected to be IDENTICAL; the
+tests assert max-abs error <= TOL and report whether the match was bit-exact.  Ray-bounce counts (integer
+work) must be equal.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # north_star tolerance for fp32 RGB
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCENES = os.path.join(ROOT, "scenes")
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = load_package()
+    p.lib()   # raises if libptamd.so is missing: there is no fallback path
+    return p
+
+
+def gpu_render(pkg, scene, w, h, depth, iters=1, iter_first=1, image=None, rotat=0, **opts):
+    sc = pkg.SceneFile(os.path.join(SCENES, scene), rotat)
+    sc.set_resolution(w, h)
+    with pkg.Renderer(0) as r:
+        r.set_options(depth=depth, **opts)
+        r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
+        r.set_camera(sc.camera)
+        if image is None:
+            r.clear_image()
+        else:
+            r.upload_image(image)
+        r.render(iter_first, iters)
+        img = r.download_image()
+        st = r.stats()
+    return img, [int(x) for x in st.live_in[:depth]], st
+
+
+def cpu_render(scene, w, h, depth, iters=1, iter_first=1, image=None, rotat=0, rr_start=-1, seed=0):
+    sc = O.LoadedScene(os.path.join(SCENES, scene), rotat)
+    sc.set_resolution(w, h)
+    img, live = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, depth, iters=iters,
+                         iter_first=iter_first, rr_start=rr_start, seed=seed, image=image)
+    return img, [int(x) for x in live]
+
+
+def check(gpu, cpu, live_g, live_c, what):
+    err = float(np.abs(gpu - cpu).max())
+    exact = bool((gpu.view(np.uint32) == cpu.view(np.uint32)).all())
+    print(f"{what}: max|GPU-CPU| = {err:g}, bit-exact = {exact}, ray-bounces = {sum(live_g)}")
+    assert err <= TOL, what
+    assert live_g == live_c, f"{what}: live-ray counts differ {live_g} vs {live_c}"
+    assert np.isfinite(gpu).all()
+
+
+# ---------------------------------------------------------------- BASELINE config 1 and friends
+def test_config1_sample_scene_400x400_depth4(pkg):
+    """BASELINE.json configs[0]: sampleScene.txt, 400x400, 1 spp, 4 bounces, fixed seed."""
+    g, lg, _ = gpu_render(pkg, "sampleScene.txt", 400, 400, 4)
+    c, lc = cpu_render("sampleScene.txt", 400, 400, 4)
+    check(g, c, lg, lc, "config1")
+    assert lg[0] == 160000 and all(a >= b for a, b in zip(lg, lg[1:]))
+    assert g.max() > 0     # some paths reach the light
+
+
+def test_config1_degrees(pkg):
+    g, lg, _ = gpu_render(pkg, "sampleScene.txt", 400, 400, 4, rotat=1)
+    c, lc = cpu_render("sampleScene.txt", 400, 400, 4, rotat=1)
+    check(g, c, lg, lc, "config1 rotat=degrees")
+
+
+def test_russian_roulette(pkg):
+    g, lg, _ = gpu_render(pkg, "sampleScene.txt", 200, 200, 8, rr_start=2)
+    c, lc = cpu_render("sampleScene.txt", 200, 200, 8, rr_start=2)
+    check(g, c, lg, lc, "russian roulette")
+    g0, lg0, _ = gpu_render(pkg, "sampleScene.txt", 200, 200, 8)
+    assert sum(lg) < sum(lg0)      # roulette removes rays
+
+
+def test_specular_scene(pkg):
+    g, lg, _ = gpu_render(pkg, "sampleScene_spec.txt", 320, 180, 8, rotat=1)
+    c, lc = cpu_render("sampleScene_spec.txt", 320, 180, 8, rotat=1)
+    check(g, c, lg, lc, "diffuse+specular")
+
+
+def test_glass_scene(pkg):
+    g, lg, _ = gpu_render(pkg, "cornell_glass.txt", 320, 180, 16, rotat=1)
+    c, lc = cpu_render("cornell_glass.txt", 320, 180, 16, rotat=1)
+    check(g, c, lg, lc, "glass (refraction + fresnel)")
+
+
+def test_cloud_256_primitives(pkg):
+    g, lg, _ = gpu_render(pkg, "cloud256.txt", 160, 90, 6, rotat=1, rr_start=3)
+    c, lc = cpu_render("cloud256.txt", 160, 90, 6, rotat=1, rr_start=3)
+    check(g, c, lg, lc, "256-primitive cloud")
+
+
+def test_seed_changes_image(pkg):
+    a, _, _ = gpu_render(pkg, "sampleScene.txt", 128, 128, 4, seed=0)
+    b, lb, _ = gpu_render(pkg, "sampleScene.txt", 128, 128, 4, seed=7)
+    c, lc = cpu_render("sampleScene.txt", 128, 128, 4, seed=7)
+    assert not np.array_equal(a, b)
+    check(b, c, lb, lc, "seed=7")
+
+
+# ---------------------------------------------------------------- accumulation / statelessness
+def test_multi_iteration_running_mean(pkg):
+    g, lg, st = gpu_render(pkg, "sampleScene.txt", 160, 120, 5, iters=6)
+    c, lc = cpu_render("sampleScene.txt", 160, 120, 5, iters=6)
+    check(g, c, lg, lc, "6 iterations")
+    assert st.iterations == 6
+
+
+def test_resume_from_host_image(pkg):
+    """(image, iteration) is a complete state: 1..3 then 4..6 from the downloaded image == 1..6."""
+    full, lf, _ = gpu_render(pkg, "sampleScene.txt", 96, 64, 4, iters=6)
+    half, lh, _ = gpu_render(pkg, "sampleScene.txt", 96, 64, 4, iters=3)
+    rest, lr, _ = gpu_render(pkg, "sampleScene.txt", 96, 64, 4, iters=3, iter_first=4, image=half)
+    assert np.array_equal(full, rest)
+    assert [a + b for a, b in zip(lh, lr)] == lf
+
+
+def test_render_iteration_reference_protocol(pkg):
+    """pt_render_iteration == one cudaRaytraceCore call: host image in/out each call (ref src/main.cpp:93-113)."""
+    sc = pkg.SceneFile(os.path.join(SCENES, "sampleScene.txt"))
+    sc.set_resolution(64, 48)
+    host = np.zeros((48, 64, 3), dtype=np.float32)
+    with pkg.Renderer(0) as r:
+        r.set_options(depth=3)
+        r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
+        r.set_camera(sc.camera)
+        for it in range(1, 5):
+            r.render_iteration(it, host_image=host)
+    c, _ = cpu_render("sampleScene.txt", 64, 48, 3, iters=4)
+    assert float(np.abs(host - c).max()) <= TOL
+
+
+# ---------------------------------------------------------------- invariants of compaction / launch shape
+def test_compaction_on_off_identical(pkg):
+    a, la, _ = gpu_render(pkg, "sampleScene_spec.txt", 200, 150, 6, compaction=1)
+    b, lb, _ = gpu_render(pkg, "sampleScene_spec.txt", 200, 150, 6, compaction=0)
+    assert np.array_equal(a, b)
+    assert la == lb
+
+
+@pytest.mark.parametrize("wg", [64, 128, 256, 512, 1024])
+def test_workgroup_size_invariance(pkg, wg):
+    ref, lr, _ = gpu_render(pkg, "sampleScene.txt", 150, 100, 5)
+    a, la, _ = gpu_render(pkg, "sampleScene.txt", 150, 100, 5, workgroup=wg)
+    assert np.array_equal(a, ref) and la == lr
+
+
+def test_geometry_path_lds_vs_scalar(pkg):
+    a, la, _ = gpu_render(pkg, "cloud256.txt", 128, 72, 4, geom_path=0, rotat=1)
+    b, lb, _ = gpu_render(pkg, "cloud256.txt", 128, 72, 4, geom_path=1, rotat=1)
+    assert np.array_equal(a, b) and la == lb
+
+
+def test_graph_vs_eager(pkg):
+    a, la, _ = gpu_render(pkg, "sampleScene.txt", 128, 96, 4, iters=5, use_graph=1)
+    b, lb, _ = gpu_render(pkg, "sampleScene.txt", 128, 96, 4, iters=5, use_graph=0)
+    assert np.array_equal(a, b) and la == lb
+
+
+def test_tiles_reassemble_to_full_frame(pkg):
+    """Pixel sharding: rows split over contexts, RNG keyed on the global pixel -> bit-identical union."""
+    W, H, depth = 120, 90, 5
+    full, lf, _ = gpu_render(pkg, "sampleScene.txt", W, H, depth, iters=2)
+    parts, live = [], [0] * depth
+    for r0, r1 in ((0, 17), (17, 64), (64, 90)):
+        t, lt, _ = gpu_render(pkg, "sampleScene.txt", W, H, depth, iters=2, row_begin=r0, row_end=r1)
+        assert t.shape == (r1 - r0, W, 3)
+        parts.append(t)
+        live = [a + b for a, b in zip(live, lt)]
+    assert np.array_equal(np.concatenate(parts, axis=0), full)
+    assert live == lf
+
+
+# ---------------------------------------------------------------- edge cases
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 3), (65, 1), (64, 64), (37, 23), (257, 5)])
+def test_ragged_resolutions(pkg, w, h):
+    g, lg, _ = gpu_render(pkg, "sampleScene.txt", w, h, 3)
+    c, lc = cpu_render("sampleScene.txt", w, h, 3)
+    check(g, c, lg, lc, f"{w}x{h}")
+
+
+def test_depth_one_and_max(pkg):
+    g, lg, _ = gpu_render(pkg, "sampleScene.txt", 64, 64, 1)
+    c, lc = cpu_render("sampleScene.txt", 64, 64, 1)
+    check(g, c, lg, lc, "depth 1")
+    g, lg, _ = gpu_render(pkg, "sampleScene.txt", 48, 32, 64, rr_start=3)
+    c, lc = cpu_render("sampleScene.txt", 48, 32, 64, rr_start=3)
+    check(g, c, lg, lc, "depth 64")
+
+
+def test_empty_scene_is_black(pkg):
+    sc = pkg.SceneFile(os.path.join(SCENES, "sampleScene.txt"))
+    sc.set_resolution(32, 32)
+    with pkg.Renderer(0) as r:
+        r.set_options(depth=4)
+        r.set_scene(sc.geoms, 0, sc.mats, sc.n_materials)
+        r.set_camera(sc.camera)
+        r.upload_image(np.ones((32, 32, 3), dtype=np.float32))
+        r.render(1, 1)
+        img = r.download_image()
+        st = r.stats()
+    assert (img == 0).all()
+    assert [int(x) for x in st.live_in[:4]] == [1024, 0, 0, 0]
+
+
+def test_axis_parallel_rays_hit_boxes(pkg):
+    """Camera looking straight down an axis at an axis-aligned box: slab divisions by exactly 0."""
+    geoms = (O.StaticGeom * 2)(O.make_geom(O.CUBE, 0, (0, 0, -5), (0, 0, 0), (2, 2, 2)),
+                               O.make_geom(O.CUBE, 1, (0, 0, 3), (0, 0, 0), (20, 20, .1)))
+    mats = (O.Material * 2)(O.make_material(color=(.5, .6, .7)), O.make_material(emittance=2.0))
+    cam = O.make_camera(33, 33, (0, 0, 0), (0, 0, -1), (0, 1, 0), 20)
+    ref, live = O.render(geoms, 2, mats, 2, cam, 3, iters=2)
+    with pkg.Renderer(0) as r:
+        r.set_options(depth=3)
+        r.set_scene(C.cast(geoms, C.POINTER(pkg.StaticGeom)), 2, C.cast(mats, C.POINTER(pkg.Material)), 2)
+        r.set_camera(pkg.CameraData.from_buffer_copy(cam))
+        r.clear_image()
+        r.render(1, 2)
+        img = r.download_image()
+        st = r.stats()
+    check(img, ref, [int(x) for x in st.live_in[:3]], [int(x) for x in live], "axis-parallel")
+    assert img.max() > 0
+
+
+def test_pbo_matches_oracle(pkg):
+    import torch
+    W, H = 96, 64
+    sc = pkg.SceneFile(os.path.join(SCENES, "sampleScene.txt"))
+    sc.set_resolution(W, H)
+    pbo = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda:0")
+    with pkg.Renderer(0) as r:
+        r.set_options(depth=4)
+        r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
+        r.set_camera(sc.camera)
+        r.clear_image()
+        r.render(1, 3)
+        r.send_image_to_pbo(pbo.data_ptr())
+        r.synchronize()
+        img = r.download_image()
+    want = np.zeros((H * W, 4), dtype=np.uint8)
+    O.lib().o_sendImageToPBO(want.ctypes.data, H * W, np.ascontiguousarray(img).ctypes.data)
+    assert np.array_equal(pbo.cpu().numpy().reshape(-1, 4), want)
+
+
+def test_bound_external_framebuffer_and_stream(pkg):
+    """The context renders into caller-owned device memory on a caller-owned stream (torch = plumbing)."""
+    import torch
+    W, H = 80, 60
+    sc = pkg.SceneFile(os.path.join(SCENES, "sampleScene.txt"))
+    sc.set_resolution(W, H)
+    fb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+    stream = torch.cuda.Stream()
+    with pkg.Renderer(0) as r:
+        r.set_options(depth=4)
+        r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
+        r.set_camera(sc.camera)
+        r.bind_image(fb.data_ptr())
+        r.set_stream(stream.cuda_stream)
+        r.render(1, 2)
+        r.synchronize()
+    c, _ = cpu_render("sampleScene.txt", W, H, 4, iters=2)
+    assert float(np.abs(fb.cpu().numpy() - c).max()) <= TOL
+
+
+def test_errors_are_reported_not_fatal(pkg):
+    with pkg.Renderer(0) as r:
+        with pytest.raises(pkg.PtError):
+            r.render(1, 1)                       # no scene yet
+        with pytest.raises(pkg.PtError):
+            r.set_options(depth=0)
+        sc = pkg.SceneFile(os.path.join(SCENES, "sampleScene.txt"))
+        sc.geoms[0].materialid = 99
+        with pytest.raises(pkg.PtError):
+            r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
+    assert pkg.lib().pt_create(999, C.byref(C.c_void_p())) != 0
+
+
+# ---------------------------------------------------------------- full-size properties (oracle too slow here)
+def test_full_size_properties_1080p(pkg):
+    """BASELINE configs[1] shape (1920x1080, 8 bounces): determinism, conservation, tiling, sample rows vs oracle."""
+    W, H, depth = 1920, 1080, 8
+    a, la, st = gpu_render(pkg, "sampleScene_spec.txt", W, H, depth, iters=2)
+    b, lb, _ = gpu_render(pkg, "sampleScene_spec.txt", W, H, depth, iters=2, workgroup=512, compaction=0)
+    assert np.array_equal(a, b) and la == lb                      # order / launch-shape independent
+    assert la[0] == 2 * W * H and all(x >= y for x, y in zip(la, la[1:]))
+    assert np.isfinite(a).all() and a.min() >= 0
+    top, lt, _ = gpu_render(pkg, "sampleScene_spec.txt", W, H, depth, iters=2, row_begin=0, row_end=540)
+    bot, lb2, _ = gpu_render(pkg, "sampleScene_spec.txt", W, H, depth, iters=2, row_begin=540, row_end=1080)
+    assert np.array_equal(np.concatenate([top, bot]), a)
+    assert [x + y for x, y in zip(lt, lb2)] == la
+    # oracle on a few full-width rows of the same frame (single paths, both iterations)
+    sc = O.LoadedScene(os.path.join(SCENES, "sampleScene_spec.txt"))
+    sc.set_resolution(W, H)
+    opt = O.Options(depth, -1, 0, O.TRIG_POLY)
+    L = O.lib()
+    for y in (0, 333, 540, 1079):
+        for x in range(0, W, 16):
+            l1 = L.o_trace_path(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, C.byref(sc.camera), C.byref(opt), x, y, 1, None)
+            l2 = L.o_trace_path(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, C.byref(sc.camera), C.byref(opt), x, y, 2, None)
+            want = [np.float32((np.float32(np.float32(u * np.float32(1.0)) * np.float32(1.0) + np.float32(v))) / np.float32(2.0))
+                    for u, v in zip(l1.tup(), l2.tup())]
+            # running mean: it=1 -> (0*0 + L1)/1 = L1 ; it=2 -> (L1*1 + L2)/2
+            assert np.allclose(a[y, x], want, atol=TOL, rtol=0), (x, y)
