@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- ray-bounces/s of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One *step* = one iteration (1 sample per pixel) of the hot path over the whole frame: camera rays, up to
+`depth` bounce launches (intersect + shade + compaction), framebuffer accumulate.  At N=1 the workload is
+BASELINE.json configs[1]: the bundled sampleScene at 1920x1080, 8 bounces, diffuse+specular, K=256 steps =
+its 256 spp.  For N>1 (launched by torch.distributed.run, one rank per GPU) the frame grows with N at fixed
+aspect and camera (N=4 is configs[3]'s 3840x2160) and every rank renders one band of rows of it: per-GPU work
+is fixed ("weak"), no collective on the data path during rendering, and ONE RCCL gather of the framebuffer
+bands to rank 0 at the end of the timed region (the path's only real exchange step).
+
+Prints ONE JSON line (rank 0).  `value` = ray-bounces of all ranks / wall time, in Mray-bounces/s, with
+inputs resident in HBM before the timed region.  The `roofline` block prices the dominant kernel (k_bounce)
+against HBM: algorithmic bytes / HIP-event kernel time.  `cpu_baseline` times the CPU oracle
+on a bounded sample of the same workload on this box's host cores (rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--scene", default="sampleScene_spec.txt")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--rr-start", type=int, default=-1)
+    ap.add_argument("--rotat", choices=["radians", "degrees"], default="radians")
+    ap.add_argument("--workgroup", type=int, default=0)
+    ap.add_argument("--geom-path", type=int, default=0)
+    ap.add_argument("--no-compaction", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
+                    help="PMC-derived HBM bytes per launch (written by profiles/collect_pmc.py), if present")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, scene_path, rotat):
+    """Oracle (kind 'port') on all host cores, bounded sample: full frame, as many spp as fit ~cpu-seconds."""
+    import numpy as np  # noqa: F401
+    import oracle_lib as O
+    O.build()
+    sc = O.LoadedScene(scene_path, rotat)
+    sc.set_resolution(args.width, args.height)
+    cores = os.cpu_count() or 1
+    # calibration pass on a strip of rows (same scene, same depth) to size the sample
+    t0 = time.perf_counter()
+    sc_small = O.LoadedScene(scene_path, rotat)
+    sc_small.set_resolution(args.width // 4, args.height // 4)
+    _, live = O.render(sc_small.geoms, sc_small.n_objects, sc_small.mats, sc_small.n_materials, sc_small.camera,
+                       args.depth, iters=1, rr_start=args.rr_start, nthreads=cores)
+    dt = time.perf_counter() - t0
+    est_full = dt * 16.0
+    spp = max(1, min(64, int(args.cpu_seconds / max(est_full, 1e-3))))
+    t0 = time.perf_counter()
+    _, live = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, args.depth, iters=spp,
+                       rr_start=args.rr_start, nthreads=cores)
+    dt = time.perf_counter() - t0
+    rb = int(live.sum())
+    return {"value": rb / dt / 1e6, "unit": "Mray-bounces/s", "cores": cores, "kind": "port",
+            "sample": f"{args.width}x{args.height} x {spp} spp x {args.depth} bounces of the same scene "
+                      f"({rb} ray-bounces in {dt:.2f} s, oracle/pt_oracle.c, {cores} threads)",
+            "ms_per_frame": dt / spp * 1e3}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    pkg.lib()     # fails loudly when libptamd.so is missing: no fallback path
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the render path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    rotat = pkg.ROTAT_DEGREES if args.rotat == "degrees" else pkg.ROTAT_RADIANS
+    scene_path = os.path.join(ROOT, "scenes", args.scene)
+    sc = pkg.SceneFile(scene_path, rotat)
+    # weak scaling: the frame grows with the GPU count at fixed aspect and camera (N=4 is BASELINE configs[3]'s
+    # 3840x2160), so every rank owns a band of ~1920*1080 pixels of the same picture
+    s = float(world) ** 0.5
+    W = args.width if world == 1 else int(round(args.width * s / 16.0)) * 16
+    Hfull = args.height if world == 1 else int(round(args.height * s / 2.0)) * 2
+    sc.set_resolution(W, Hfull)
+    r0, r1 = Hfull * rank // world, Hfull * (rank + 1) // world
+    Hband = r1 - r0
+    Hmax = max(Hfull * (k + 1) // world - Hfull * k // world for k in range(world))
+
+    fb = torch.zeros((Hmax, W, 3), dtype=torch.float32, device=dev)
+    r = pkg.Renderer(local_rank)
+    r.set_options(depth=args.depth, rr_start=args.rr_start, workgroup=args.workgroup, geom_path=args.geom_path,
+                  compaction=0 if args.no_compaction else 1, use_graph=0 if args.no_graph else 1,
+                  row_begin=r0 if world > 1 else 0, row_end=r1 if world > 1 else 0)
+    r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
+    r.set_camera(sc.camera)
+    r.bind_image(fb.data_ptr())
+    gathered = [torch.empty_like(fb) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def sync():
+        r.synchronize()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+            torch.cuda.synchronize(dev)
+
+    # warmup (untimed): also captures the per-iteration hipGraph
+    if args.warmup > 0:
+        r.render(1, args.warmup)
+    if world > 1:
+        dist.gather(fb, gathered, dst=0)
+    sync()
+    r.reset_stats()
+
+    # timed region: exactly K steps (+ the one framebuffer gather for N>1)
+    first = args.warmup + 1
+    sync()
+    t0 = time.perf_counter()
+    r.render(first, args.steps)
+    r.synchronize()
+    if world > 1:
+        dist.gather(fb, gathered, dst=0)
+    sync()
+    dt = time.perf_counter() - t0
+
+    st = r.stats()
+    rb_local = int(st.ray_bounces)
+    live_in = [int(x) for x in st.live_in[:args.depth]]
+    tens = torch.tensor([dt, float(rb_local), float(st.gpu_ms)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tens.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tens.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_max, rb_total = float(tmax[0]), float(tsum[1])
+    else:
+        dt_max, rb_total = dt, float(rb_local)
+
+    if rank == 0:
+        npix = W * Hband
+        alg_bytes = pkg.algorithmic_bytes(npix, live_in, args.steps)      # this rank, the timed K steps
+        # dominant kernel: k_bounce, one HIP event pair per launch on the render stream (a few extra steps)
+        prof_steps = 8
+        r.reset_stats()
+        bounce_ms = r.render_profiled(first + args.steps, prof_steps)
+        pst = r.stats()
+        p_live = [int(x) for x in pst.live_in[:args.depth]]
+        p_bytes = pkg.algorithmic_bytes(npix, p_live, prof_steps)
+        p_ms = sum(bounce_ms)
+        launches = prof_steps * args.depth
+        achieved = p_bytes / (p_ms * 1e-3) / 1e9
+        traffic = None
+        if os.path.exists(args.traffic_json):
+            try:
+                with open(args.traffic_json) as f:
+                    traffic = json.load(f).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "ray-bounces/sec",
+            "value": rb_total / dt_max / 1e6,
+            "unit": "Mray-bounces/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.scene} {W}x{Hfull} ({world} row band(s) of ~{W}x{Hmax}), {args.steps} spp, "
+                            f"{args.depth} bounces, diffuse+specular, rotat={args.rotat}, rr_start={args.rr_start}",
+                "scene": args.scene, "width": W, "height": Hfull, "depth": args.depth, "spp": args.steps,
+                "rotat_units": args.rotat, "primitives": sc.n_objects, "materials": sc.n_materials,
+                "compaction": not args.no_compaction, "hip_graph": not args.no_graph,
+                "parallelism": f"pixel-bands x{world}" + (", 1 RCCL gather" if world > 1 else ""),
+            },
+            "ray_bounces": int(rb_total),
+            "live_in_per_bounce": live_in,
+            "ms_per_frame_1spp": dt_max / args.steps * 1e3,
+            "total_ms": dt_max * 1e3,
+            "gpu_event_ms": float(st.gpu_ms),
+            "algorithmic_bytes_timed_region": alg_bytes,
+            "algorithmic_GBs_whole_job": alg_bytes / dt_max / 1e9,
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "pt::k_bounce",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "bytes_per_launch": p_bytes / launches,
+                "avg_launch_ms": p_ms / launches,
+                "launches_measured": launches,
+                "bytes_per_ray_bounce": p_bytes / max(1, sum(p_live)),
+                "note": "achieved = algorithmic bytes (SURVEY 8(d): P*40 + sum_b(live_in+live_out)*40 + P*24 per "
+                        "iteration) / summed k_bounce launch time from per-launch HIP events; the path is "
+                        "VALU/latency-bound, see DESIGN.md",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, scene_path, rotat)
+        print(json.dumps(out), flush=True)
+
+    r.close()
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

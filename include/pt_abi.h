@@ -143,6 +143,10 @@ int  pt_render_iteration(pt_ctx *ctx, pt_uchar4 *device_pbo_or_null, float *host
 /* ---- measurement ---- */
 int  pt_get_stats(pt_ctx *ctx, pt_stats *out);        /* synchronizes the render stream */
 int  pt_reset_stats(pt_ctx *ctx);
+/* Like pt_render (eager launches), but every per-bounce kernel launch is bracketed by its own pair of HIP
+ * events on the render stream; bounce_ms_out[b] (depth entries) receives the summed duration of bounce b's
+ * launches over the rendered iterations.  Synchronous.  For roofline accounting, not for throughput. */
+int  pt_render_profiled(pt_ctx *ctx, int iter_first, int iter_count, double *bounce_ms_out);
 
 /* ---- scene files (ref: src/scene.cpp, src/utilities.cpp:74-90; format README.md:160-217) ---- */
 enum { PT_ROTAT_RADIANS = 0,   /* what the reference binary does (GLM_FORCE_RADIANS, ref: src/utilities.cpp:7) */

@@ -128,6 +128,7 @@ def lib():
         "pt_render_iteration": (i, [vp, vp, vp, i]),
         "pt_get_stats": (i, [vp, P(Stats)]),
         "pt_reset_stats": (i, [vp]),
+        "pt_render_profiled": (i, [vp, i, i, P(C.c_double)]),
         "pt_scene_load": (i, [cp, i, P(vp)]),
         "pt_scene_free": (None, [vp]),
         "pt_scene_counts": (i, [vp, P(i), P(i), P(i)]),
@@ -259,6 +260,12 @@ class Renderer:
         s = Stats()
         _check(self.L.pt_get_stats(self.h, C.byref(s)), "pt_get_stats")
         return s
+
+    def render_profiled(self, iter_first, iter_count):
+        """Per-bounce kernel time (ms, summed over the iterations), one HIP event pair per launch."""
+        ms = (C.c_double * PT_MAX_DEPTH)()
+        _check(self.L.pt_render_profiled(self.h, iter_first, iter_count, ms), "pt_render_profiled")
+        return [float(ms[b]) for b in range(self.opt.depth)]
 
     def reset_stats(self):
         _check(self.L.pt_reset_stats(self.h), "pt_reset_stats")

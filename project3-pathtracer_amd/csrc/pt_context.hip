@@ -474,6 +474,41 @@ int pt_render(pt_ctx *c, int iter_first, int iter_count)
     return PT_OK;
 }
 
+int pt_render_profiled(pt_ctx *c, int iter_first, int iter_count, double *bounce_ms_out)
+{
+    if (!c || !bounce_ms_out) return fail(PT_ERR_INVALID, "pt_render_profiled: NULL argument");
+    if (iter_first < 1 || iter_count < 0) return fail(PT_ERR_INVALID, "pt_render_profiled: iterations [%d,+%d)", iter_first, iter_count);
+    int rc = configure(c);
+    if (rc != PT_OK) return rc;
+    const int depth = c->kp.depth;
+    for (int b = 0; b < depth; ++b) bounce_ms_out[b] = 0.0;
+    if (iter_count == 0) return PT_OK;
+    hipStream_t s = c->stream;
+    std::vector<hipEvent_t> ev((size_t)2 * (size_t)depth);
+    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(pt::launch_iter_set(s, c->d_state, (uint32_t)(iter_first - 1)));
+    for (int i = 0; i < iter_count; ++i) {
+        HIP_TRY(pt::launch_iter_begin(s, c->d_state, c->kp.npix, depth, c->cfg.compact));
+        for (int b = 0; b < depth; ++b) {
+            HIP_TRY(hipEventRecord(ev[2 * b], s));
+            HIP_TRY(pt::launch_bounce(s, c->kp, c->cfg, b));
+            HIP_TRY(hipEventRecord(ev[2 * b + 1], s));
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        for (int b = 0; b < depth; ++b) {
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, ev[2 * b], ev[2 * b + 1]));
+            bounce_ms_out[b] += (double)ms;
+        }
+    }
+    HIP_TRY(pt::launch_iter_fold(s, c->d_state, depth));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    c->bounce_launches += (unsigned long long)iter_count * (unsigned long long)depth;
+    c->image_valid = true;
+    return PT_OK;
+}
+
 int pt_send_image_to_pbo(pt_ctx *c, pt_uchar4 *device_pbo)
 {
     if (!c || !device_pbo) return fail(PT_ERR_INVALID, "pt_send_image_to_pbo: NULL argument");
