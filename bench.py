@@ -59,7 +59,11 @@ def cpu_baseline(args, scene_path, rotat):
     O.build()
     sc = O.LoadedScene(scene_path, rotat)
     sc.set_resolution(args.width, args.height)
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("PT_BENCH_CPU_THREADS", "16"))))   # a 1-GPU box's CPU share
     # calibration pass on a strip of rows (same scene, same depth) to size the sample
     t0 = time.perf_counter()
     sc_small = O.LoadedScene(scene_path, rotat)
@@ -110,13 +114,12 @@ def main():
     sc = pkg.SceneFile(scene_path, rotat)
     # weak scaling: the frame grows with the GPU count at fixed aspect and camera (N=4 is BASELINE configs[3]'s
     # 3840x2160), so every rank owns a band of ~1920*1080 pixels of the same picture
-    s = float(world) ** 0.5
-    W = args.width if world == 1 else int(round(args.width * s / 16.0)) * 16
-    Hfull = args.height if world == 1 else int(round(args.height * s / 2.0)) * 2
+    from project3_pathtracer_amd import sharding
+    W, Hfull = sharding.weak_scaled_frame(args.width, args.height, world)
     sc.set_resolution(W, Hfull)
-    r0, r1 = Hfull * rank // world, Hfull * (rank + 1) // world
+    r0, r1 = sharding.band_rows(Hfull, world, rank)
     Hband = r1 - r0
-    Hmax = max(Hfull * (k + 1) // world - Hfull * k // world for k in range(world))
+    Hmax = sharding.max_band_rows(Hfull, world)
 
     fb = torch.zeros((Hmax, W, 3), dtype=torch.float32, device=dev)
     r = pkg.Renderer(local_rank)
@@ -126,7 +129,6 @@ def main():
     r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
     r.set_camera(sc.camera)
     r.bind_image(fb.data_ptr())
-    gathered = [torch.empty_like(fb) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     def sync():
         r.synchronize()
@@ -139,7 +141,7 @@ def main():
     if args.warmup > 0:
         r.render(1, args.warmup)
     if world > 1:
-        dist.gather(fb, gathered, dst=0)
+        frame = sharding.gather_bands(fb, Hfull, world, rank, dist=dist, dst=0)   # RCCL over xGMI
     sync()
     r.reset_stats()
 
@@ -150,7 +152,7 @@ def main():
     r.render(first, args.steps)
     r.synchronize()
     if world > 1:
-        dist.gather(fb, gathered, dst=0)
+        frame = sharding.gather_bands(fb, Hfull, world, rank, dist=dist, dst=0)   # RCCL over xGMI
     sync()
     dt = time.perf_counter() - t0
 

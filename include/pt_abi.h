@@ -83,7 +83,8 @@ typedef struct pt_options {
     unsigned seed;        /* RNG stream selector (default 0) */
     int compaction;       /* 1 = compact live rays after every bounce (default), 0 = rays keep their slot */
     int workgroup;        /* threads per workgroup: 64, 128, 256, 512 or 1024 (default 0 = library choice) */
-    int geom_path;        /* 0 = primitives through scalar (SGPR) loads, 1 = primitives staged in LDS (default 0) */
+    int geom_path;        /* how primitives reach the lanes: 0 = library choice (default), 1 = scalar (SGPR) loads,
+                             2 = staged in LDS, 3 = scalar candidate test + wave-private LDS hit queue */
     int row_begin;        /* tile rendered by this context: rows [row_begin, row_end) of the frame; */
     int row_end;          /*   0,0 = the whole frame.  RNG streams are keyed on the global pixel index. */
     int use_graph;        /* 1 = replay one captured hipGraph per iteration (default), 0 = eager launches */

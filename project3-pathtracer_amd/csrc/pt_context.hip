@@ -228,7 +228,8 @@ int configure(pt_ctx *c)
     // launch shape: persistent workgroups, as many as are resident at once
     pt::LaunchCfg &cfg = c->cfg;
     cfg.workgroup = o.workgroup ? o.workgroup : 256;
-    cfg.geom_lds = o.geom_path == 1;
+    // library choice: the hit queue pays when most primitives are hit by some lane of every wave (small scenes)
+    cfg.geom = o.geom_path == 0 ? (k.nG <= 32 ? 2 : 0) : o.geom_path - 1;
     cfg.compact = o.compaction != 0;
     const size_t lds = pt::bounce_lds_bytes(k, cfg);
     if (lds > 160 * 1024) return fail(PT_ERR_INVALID, "scene needs %zu B of LDS per workgroup (> 160 KiB)", lds);
@@ -334,7 +335,7 @@ int pt_set_options(pt_ctx *c, const pt_options *o)
     const int wg = o->workgroup;
     if (!(wg == 0 || wg == 64 || wg == 128 || wg == 256 || wg == 512 || wg == 1024))
         return fail(PT_ERR_INVALID, "workgroup %d not one of 0,64,128,256,512,1024", wg);
-    if (o->geom_path != 0 && o->geom_path != 1) return fail(PT_ERR_INVALID, "geom_path %d not 0 or 1", o->geom_path);
+    if (o->geom_path < 0 || o->geom_path > 3) return fail(PT_ERR_INVALID, "geom_path %d not in 0..3", o->geom_path);
     if (o->row_begin < 0 || o->row_end < o->row_begin) return fail(PT_ERR_INVALID, "tile rows [%d,%d)", o->row_begin, o->row_end);
     c->opt = *o;
     c->dirty = true;

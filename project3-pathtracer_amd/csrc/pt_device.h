@@ -122,57 +122,87 @@ __device__ __forceinline__ f3 mulMV(const float *m, f3 v, float w)
 __device__ __forceinline__ f3 pointOnRay(f3 o, f3 d, float t) { return o + (t - .0001f) * normalize(d); }
 
 // ---------------------------------------------------------------------------------------------
-// One primitive against one ray.  Returns the world-space distance or -1; on a hit fills point/normal.
+// One primitive against one ray, split into the three stages the kernels schedule separately:
+//   candidateT   object-space ray + parametric distance t (wave-uniform primitive, all lanes busy)
+//   hitPoint     world-space hit point and distance for one (ray, primitive, t) candidate
+//   hitNormal    world-space normal of the winning candidate
 // sphere: ref src/intersections.h:81-117 (bit-faithful, including the double-precision radicand);
 // cube:   the reference's stub (src/intersections.h:72-77) defined as a slab test in object space
 //         (DESIGN.md "Canonical semantics", box).
-// `g` is wave-uniform; the type branch is a scalar branch.
+// Box face code: bits 1..0 = axis, bit 2 = 1 when the object-space normal points along -axis.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float intersectPrim(const Prim &g, f3 o, f3 d, f3 &point, f3 &normal)
+__device__ __forceinline__ bool candidateT(uint32_t type, const float *inv, f3 o, f3 d, f3 &ro, f3 &rd, float &t,
+                                           uint32_t &face)
 {
-    if (g.type > 1u) return -1.0f;                       // MESH: parsed by the loader, never has geometry
-    f3 ro = mulMV(g.inv, o, 1.0f);
-    f3 rd = normalize(mulMV(g.inv, d, 0.0f));
-    float t;
-    f3 nobj;
-    if (g.type == 0u) {
+    face = 0u;
+    t = 0.0f;
+    if (type > 1u) return false;                         // MESH: parsed by the loader, never has geometry
+    ro = mulMV(inv, o, 1.0f);
+    rd = normalize(mulMV(inv, d, 0.0f));
+    if (type == 0u) {
         float vDot = dot(ro, rd);
         float radicand = (float)((double)(vDot * vDot) - ((double)dot(ro, ro) - 0.25));
-        if (radicand < 0) return -1.0f;
+        if (radicand < 0) return false;
         float squareRoot = sqrtf(radicand);
         float firstTerm = -vDot;
         float t1 = firstTerm + squareRoot;
         float t2 = firstTerm - squareRoot;
-        if (t1 < 0 && t2 < 0) return -1.0f;
+        if (t1 < 0 && t2 < 0) return false;
         else if (t1 > 0 && t2 > 0) t = (t2 < t1) ? t2 : t1;
         else t = (t1 < t2) ? t2 : t1;
-        nobj = mk(0, 0, 0);
-    } else {
-        float inv, t0, t1, tn, tf;
-        inv = 1.0f / rd.x; t0 = (-0.5f - ro.x) * inv; t1 = (0.5f - ro.x) * inv;
-        float tmin = (t0 < t1) ? t0 : t1, tmax = (t0 < t1) ? t1 : t0;
-        int amin = 0, amax = 0;
-        inv = 1.0f / rd.y; t0 = (-0.5f - ro.y) * inv; t1 = (0.5f - ro.y) * inv;
-        tn = (t0 < t1) ? t0 : t1; tf = (t0 < t1) ? t1 : t0;
-        if (tn > tmin) { tmin = tn; amin = 1; }
-        if (tf < tmax) { tmax = tf; amax = 1; }
-        inv = 1.0f / rd.z; t0 = (-0.5f - ro.z) * inv; t1 = (0.5f - ro.z) * inv;
-        tn = (t0 < t1) ? t0 : t1; tf = (t0 < t1) ? t1 : t0;
-        if (tn > tmin) { tmin = tn; amin = 2; }
-        if (tf < tmax) { tmax = tf; amax = 2; }
-        if (tmax < tmin || tmax < 0) return -1.0f;
-        bool entry = tmin > 0;
-        t = entry ? tmin : tmax;
-        int axis = entry ? amin : amax;
-        float da = (axis == 0) ? rd.x : (axis == 1) ? rd.y : rd.z;
-        float sgn = entry ? ((da > 0) ? -1.0f : 1.0f) : ((da > 0) ? 1.0f : -1.0f);
-        nobj = mk(axis == 0 ? sgn : 0.0f, axis == 1 ? sgn : 0.0f, axis == 2 ? sgn : 0.0f);
+        return true;
     }
-    f3 real = mulMV(g.fwd, pointOnRay(ro, rd, t), 1.0f);
-    point = real;
-    if (g.type == 0u) normal = normalize(real - mk(g.cx, g.cy, g.cz));
-    else normal = normalize(mulMV(g.fwd, nobj, 0.0f));
+    float inv1, t0, t1, tn, tf;
+    inv1 = 1.0f / rd.x; t0 = (-0.5f - ro.x) * inv1; t1 = (0.5f - ro.x) * inv1;
+    float tmin = (t0 < t1) ? t0 : t1, tmax = (t0 < t1) ? t1 : t0;
+    int amin = 0, amax = 0;
+    inv1 = 1.0f / rd.y; t0 = (-0.5f - ro.y) * inv1; t1 = (0.5f - ro.y) * inv1;
+    tn = (t0 < t1) ? t0 : t1; tf = (t0 < t1) ? t1 : t0;
+    if (tn > tmin) { tmin = tn; amin = 1; }
+    if (tf < tmax) { tmax = tf; amax = 1; }
+    inv1 = 1.0f / rd.z; t0 = (-0.5f - ro.z) * inv1; t1 = (0.5f - ro.z) * inv1;
+    tn = (t0 < t1) ? t0 : t1; tf = (t0 < t1) ? t1 : t0;
+    if (tn > tmin) { tmin = tn; amin = 2; }
+    if (tf < tmax) { tmax = tf; amax = 2; }
+    if (tmax < tmin || tmax < 0) return false;
+    const bool entry = tmin > 0;
+    t = entry ? tmin : tmax;
+    const int axis = entry ? amin : amax;
+    const float da = (axis == 0) ? rd.x : (axis == 1) ? rd.y : rd.z;
+    const bool negative = entry ? (da > 0) : !(da > 0);   // entry face looks against the ray, exit face along it
+    face = (uint32_t)axis | (negative ? 4u : 0u);
+    return true;
+}
+
+// world-space hit point = transform * getPointOnRay(object ray, t); returns the distance from the ray origin
+__device__ __forceinline__ float hitPoint(const float *fwd, f3 o, f3 ro, f3 rd, float t, f3 &real)
+{
+    real = mulMV(fwd, pointOnRay(ro, rd, t), 1.0f);
     return length(o - real);
+}
+
+__device__ __forceinline__ f3 sphereNormal(f3 real, f3 center) { return normalize(real - center); }
+__device__ __forceinline__ f3 boxNormal(const float *fwd, uint32_t face)
+{
+    const uint32_t axis = face & 3u;
+    const float sgn = (face & 4u) ? -1.0f : 1.0f;
+    const f3 nobj = mk(axis == 0u ? sgn : 0.0f, axis == 1u ? sgn : 0.0f, axis == 2u ? sgn : 0.0f);
+    return normalize(mulMV(fwd, nobj, 0.0f));
+}
+
+// the three stages back to back (direct path: hit work is done inside the wave-uniform primitive loop)
+__device__ __forceinline__ float intersectPrim(const Prim &g, f3 o, f3 d, f3 &point, f3 &normal)
+{
+    f3 ro, rd;
+    float t;
+    uint32_t face;
+    if (!candidateT(g.type, g.inv, o, d, ro, rd, t, face)) return -1.0f;
+    f3 real;
+    const float dist = hitPoint(g.fwd, o, ro, rd, t, real);
+    point = real;
+    if (g.type == 0u) normal = sphereNormal(real, mk(g.cx, g.cy, g.cz));
+    else normal = boxNormal(g.fwd, face);
+    return dist;
 }
 
 // calculateRandomDirectionInHemisphere (ref: src/interactions.h:62-87), deterministic trig

@@ -51,7 +51,7 @@ struct KParams {
 struct LaunchCfg {
     int workgroup;   // 64..1024
     int grid;        // workgroups per bounce launch
-    bool geom_lds;
+    int geom;        // 0 scalar direct, 1 LDS direct, 2 hit queue (pt_kernels.hip)
     bool compact;
 };
 

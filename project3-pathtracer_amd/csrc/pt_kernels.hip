@@ -43,8 +43,18 @@ struct Hit {
     bool any;
 };
 
-template <bool GEOM_LDS>
-__device__ __forceinline__ Hit nearestHit(const KParams &p, const Prim *s_prims, f3 o, f3 d)
+// GEOM selects how the primitive list reaches the lanes:
+//   0  direct, scalar: records through s_load into SGPRs; hit work inside the wave-uniform primitive loop
+//   1  direct, LDS:    records staged in LDS, broadcast reads; same loop
+//   2  hit queue:      the uniform loop only finds candidates (object-space t); every (ray, primitive, t)
+//                      candidate is appended to a wave-private LDS queue and the expensive hit work (world
+//                      point, distance) runs on full 64-candidate batches with every lane busy, whichever
+//                      ray or primitive a candidate belongs to.  Results flow back to the owning lane through
+//                      a 64-bit LDS atomic min on (distance bits, primitive index).
+enum { GEOM_SCALAR = 0, GEOM_LDS = 1, GEOM_QUEUE = 2 };
+
+template <int GEOM>
+__device__ __forceinline__ Hit nearestHitDirect(const KParams &p, const Prim *s_prims, f3 o, f3 d)
 {
     Hit h;
     h.any = false;
@@ -56,7 +66,7 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const Prim *s_prims,
         f3 ip, in;
         float t;
         uint32_t mat;
-        if (GEOM_LDS) {
+        if (GEOM == GEOM_LDS) {
             const Prim &P = s_prims[g];
             t = intersectPrim(P, o, d, ip, in);
             mat = P.material;
@@ -76,15 +86,125 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const Prim *s_prims,
     return h;
 }
 
-template <int WG, bool FIRST, bool GEOM_LDS, bool COMPACT>
+// wave-private LDS scratch of the hit queue
+struct WaveQueue {
+    float4 *rec;                  // [QCAP][2]: (ro.xyz, rd.x) (rd.y, rd.z, t, meta)
+    unsigned long long *key;      // [64] per owner lane: min over candidates of (distance bits << 32 | prim << 8)
+    float4 *best;                 // [64] per owner lane: (hit point xyz, meta) of the current minimum
+    float4 *org;                  // [64] per owner lane: ray origin
+};
+static constexpr uint32_t QCAP = 128;                                  // >= 63 pending + 64 appended
+static constexpr uint32_t WAVE_QUEUE_BYTES = QCAP * 32 + 64 * 8 + 64 * 16 + 64 * 16;
+static constexpr unsigned long long KEY_NONE = ~0ull;
+
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+
+// Must be entered by all 64 lanes of the wave (lanes without a ray pass valid = false): lanes are consumers
+// of queued candidates independently of their own ray.
+__device__ __forceinline__ Hit nearestHitQueued(const KParams &p, const Prim *s_prims, const WaveQueue q, f3 o, f3 d,
+                                                bool valid, uint32_t lane)
+{
+    q.key[lane] = KEY_NONE;
+    q.org[lane] = make_float4(o.x, o.y, o.z, 0.0f);
+    wave_lds_fence();
+    uint32_t qhead = 0, qtail = 0;                       // wave-uniform
+    for (int g = 0; g <= p.nG; ++g) {
+        if (g < p.nG) {
+            // candidate test: wave-uniform primitive (type + inverse transform through the scalar unit)
+            const_u32_ptr hp = (const_u32_ptr)(uintptr_t)(p.prims + g);
+            const uint32_t type = hp[0];
+            float inv[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) inv[k] = __uint_as_float(hp[4 + k]);
+            f3 ro = mk(0, 0, 0), rd = mk(0, 0, 0);
+            float t = 0.0f;
+            uint32_t face = 0u;
+            const bool cand = valid && candidateT(type, inv, o, d, ro, rd, t, face);
+            const uint64_t mask = __ballot(cand);
+            if (mask != 0ull) {
+                if (cand) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    const uint32_t pos = (qtail + rank) & (QCAP - 1u);
+                    const uint32_t meta = lane | ((uint32_t)g << 8) | (face << 28);
+                    q.rec[2 * pos] = make_float4(ro.x, ro.y, ro.z, rd.x);
+                    q.rec[2 * pos + 1] = make_float4(rd.y, rd.z, t, __uint_as_float(meta));
+                }
+                qtail += (uint32_t)__popcll(mask);
+            }
+        }
+        const uint32_t pending = qtail - qhead;
+        if (pending >= 64u || (g == p.nG && pending > 0u)) {
+            // hit work on a batch of candidates: lane l takes candidate qhead + l, whoever owns it
+            const uint32_t nb = pending < 64u ? pending : 64u;
+            wave_lds_fence();
+            unsigned long long mykey = KEY_NONE;
+            uint32_t owner = 0u;
+            float4 mine = make_float4(0, 0, 0, 0);
+            if (lane < nb) {
+                const uint32_t pos = (qhead + lane) & (QCAP - 1u);
+                const float4 r0 = q.rec[2 * pos], r1 = q.rec[2 * pos + 1];
+                const uint32_t meta = __float_as_uint(r1.w);
+                owner = meta & 63u;
+                const uint32_t prim = (meta >> 8) & 0xFFFFFu;
+                const float4 *fw = reinterpret_cast<const float4 *>(s_prims[prim].fwd);
+                const float4 f0 = fw[0], f1 = fw[1], f2 = fw[2];
+                const float fwd[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
+                const float4 oo = q.org[owner];
+                f3 real;
+                const float dist = hitPoint(fwd, mk(oo.x, oo.y, oo.z), mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), r1.z, real);
+                if (dist > 0) {                              // same admission test as the direct path: t > 0
+                    mykey = ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned long long)(prim << 8);
+                    mine = make_float4(real.x, real.y, real.z, r1.w);
+                    __hip_atomic_fetch_min(&q.key[owner], mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+            }
+            wave_lds_fence();
+            if (mykey != KEY_NONE && q.key[owner] == mykey) q.best[owner] = mine;   // unique writer: keys are unique
+            qhead += nb;
+            wave_lds_fence();
+        }
+    }
+    Hit h;
+    h.any = false;
+    h.material = 0;
+    h.p = mk(0, 0, 0);
+    h.n = mk(0, 0, 0);
+    const unsigned long long k = q.key[lane];
+    if (valid && k != KEY_NONE) {
+        const float4 b = q.best[lane];
+        const uint32_t meta = __float_as_uint(b.w);
+        const uint32_t prim = (meta >> 8) & 0xFFFFFu;
+        const uint32_t face = meta >> 28;
+        const Prim &P = s_prims[prim];                       // per-lane gather from the LDS copy
+        h.any = true;
+        h.p = mk(b.x, b.y, b.z);
+        h.material = P.material;
+        if (P.type == 0u) {
+            const float4 c = *reinterpret_cast<const float4 *>(&P.cx);
+            h.n = sphereNormal(h.p, mk(c.x, c.y, c.z));
+        } else {
+            const float4 *fw = reinterpret_cast<const float4 *>(P.fwd);
+            const float4 f0 = fw[0], f1 = fw[1], f2 = fw[2];
+            const float fwd[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
+            h.n = boxNormal(fwd, face);
+        }
+    }
+    return h;
+}
+
+template <int WG, bool FIRST, int GEOM, bool COMPACT>
 __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce)
 {
     constexpr int NW = WG / 64;
+    constexpr bool PRIMS_IN_LDS = (GEOM != GEOM_SCALAR);
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
-    // LDS carve: [prims nG*128 B (GEOM_LDS only)] [material planes nM*M_PLANES f32] [scan scratch]
+    // LDS carve: [prims nG*128 B (GEOM 1,2)] [per-wave hit queues (GEOM 2)] [material planes] [scan scratch]
     Prim *s_prims = reinterpret_cast<Prim *>(smem);
-    const int prim_bytes = GEOM_LDS ? p.nG * (int)sizeof(Prim) : 0;
-    float *s_mats = reinterpret_cast<float *>(smem + prim_bytes);
+    const int prim_bytes = PRIMS_IN_LDS ? p.nG * (int)sizeof(Prim) : 0;
+    unsigned char *s_queue = smem + prim_bytes;
+    const int queue_bytes = (GEOM == GEOM_QUEUE) ? NW * (int)WAVE_QUEUE_BYTES : 0;
+    float *s_mats = reinterpret_cast<float *>(s_queue + queue_bytes);
     const int mat_words = (p.nM * M_PLANES + 3) & ~3;
     uint32_t *s_scan = reinterpret_cast<uint32_t *>(s_mats + mat_words);   // [2][NW] wave totals, [2] bases
 
@@ -92,7 +212,16 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    if (GEOM_LDS) {
+    WaveQueue wq;
+    {
+        unsigned char *b = s_queue + wave * (int)WAVE_QUEUE_BYTES;
+        wq.rec = reinterpret_cast<float4 *>(b);
+        wq.key = reinterpret_cast<unsigned long long *>(b + QCAP * 32);
+        wq.best = reinterpret_cast<float4 *>(b + QCAP * 32 + 64 * 8);
+        wq.org = reinterpret_cast<float4 *>(b + QCAP * 32 + 64 * 8 + 64 * 16);
+    }
+
+    if (PRIMS_IN_LDS) {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.prims);
         uint4 *dst = reinterpret_cast<uint4 *>(s_prims);
         for (int k = tid; k < p.nG * 8; k += WG) dst[k] = src[k];
@@ -154,9 +283,15 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
         if (!COMPACT) live_count += (uint32_t)__popcll(__ballot(valid));
 
         bool alive = false;
+        Hit h;
+        if (GEOM == GEOM_QUEUE) {
+            h = nearestHitQueued(p, s_prims, wq, o, d, valid, (uint32_t)lane);   // whole wave, see above
+        } else {
+            h.any = false;
+            if (valid) h = nearestHitDirect<GEOM>(p, s_prims, o, d);
+        }
         if (valid) {
             f3 L = mk(0, 0, 0);
-            const Hit h = nearestHit<GEOM_LDS>(p, s_prims, o, d);
             if (h.any) {
                 const uint32_t m = h.material;
                 const float emit = s_mats[M_EMIT * p.nM + m];
@@ -322,33 +457,35 @@ __global__ __launch_bounds__(256) void k_send_image_to_pbo(pt_uchar4 *pbo, const
 // ---------------------------------------------------------------------------------------------
 size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg)
 {
-    size_t prim = cfg.geom_lds ? (size_t)p.nG * sizeof(Prim) : 0;
+    size_t prim = cfg.geom != GEOM_SCALAR ? (size_t)p.nG * sizeof(Prim) : 0;
+    size_t queue = cfg.geom == GEOM_QUEUE ? (size_t)(cfg.workgroup / 64) * WAVE_QUEUE_BYTES : 0;
     size_t mats = (size_t)((p.nM * M_PLANES + 3) & ~3) * sizeof(float);
     size_t scan = (size_t)(2 * (cfg.workgroup / 64) + 2) * sizeof(uint32_t);
-    return prim + mats + scan;
+    return prim + queue + mats + scan;
 }
 
-template <int WG, bool GEOM_LDS, bool COMPACT>
+template <int WG, int GEOM, bool COMPACT>
 static const void *bounce_fn(bool first)
 {
-    return first ? (const void *)k_bounce<WG, true, GEOM_LDS, COMPACT> : (const void *)k_bounce<WG, false, GEOM_LDS, COMPACT>;
+    return first ? (const void *)k_bounce<WG, true, GEOM, COMPACT> : (const void *)k_bounce<WG, false, GEOM, COMPACT>;
 }
 
 template <int WG>
-static const void *bounce_fn_wg(bool first, bool geom_lds, bool compact)
+static const void *bounce_fn_wg(bool first, int geom, bool compact)
 {
-    if (geom_lds) return compact ? bounce_fn<WG, true, true>(first) : bounce_fn<WG, true, false>(first);
-    return compact ? bounce_fn<WG, false, true>(first) : bounce_fn<WG, false, false>(first);
+    if (geom == GEOM_QUEUE) return compact ? bounce_fn<WG, GEOM_QUEUE, true>(first) : bounce_fn<WG, GEOM_QUEUE, false>(first);
+    if (geom == GEOM_LDS) return compact ? bounce_fn<WG, GEOM_LDS, true>(first) : bounce_fn<WG, GEOM_LDS, false>(first);
+    return compact ? bounce_fn<WG, GEOM_SCALAR, true>(first) : bounce_fn<WG, GEOM_SCALAR, false>(first);
 }
 
 static const void *select_bounce(const LaunchCfg &cfg, bool first)
 {
     switch (cfg.workgroup) {
-    case 64: return bounce_fn_wg<64>(first, cfg.geom_lds, cfg.compact);
-    case 128: return bounce_fn_wg<128>(first, cfg.geom_lds, cfg.compact);
-    case 256: return bounce_fn_wg<256>(first, cfg.geom_lds, cfg.compact);
-    case 512: return bounce_fn_wg<512>(first, cfg.geom_lds, cfg.compact);
-    case 1024: return bounce_fn_wg<1024>(first, cfg.geom_lds, cfg.compact);
+    case 64: return bounce_fn_wg<64>(first, cfg.geom, cfg.compact);
+    case 128: return bounce_fn_wg<128>(first, cfg.geom, cfg.compact);
+    case 256: return bounce_fn_wg<256>(first, cfg.geom, cfg.compact);
+    case 512: return bounce_fn_wg<512>(first, cfg.geom, cfg.compact);
+    case 1024: return bounce_fn_wg<1024>(first, cfg.geom, cfg.compact);
     default: return nullptr;
     }
 }

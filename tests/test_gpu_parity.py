@@ -159,10 +159,31 @@ def test_workgroup_size_invariance(pkg, wg):
     assert np.array_equal(a, ref) and la == lr
 
 
-def test_geometry_path_lds_vs_scalar(pkg):
-    a, la, _ = gpu_render(pkg, "cloud256.txt", 128, 72, 4, geom_path=0, rotat=1)
-    b, lb, _ = gpu_render(pkg, "cloud256.txt", 128, 72, 4, geom_path=1, rotat=1)
+def test_geometry_paths_identical(pkg):
+    """scalar-direct, LDS-direct and the LDS hit-queue nearest-hit give the same bits."""
+    a, la, _ = gpu_render(pkg, "cloud256.txt", 128, 72, 4, geom_path=1, rotat=1)
+    b, lb, _ = gpu_render(pkg, "cloud256.txt", 128, 72, 4, geom_path=2, rotat=1)
+    c, lc, _ = gpu_render(pkg, "cloud256.txt", 128, 72, 4, geom_path=3, rotat=1)
     assert np.array_equal(a, b) and la == lb
+    assert np.array_equal(a, c) and la == lc
+
+
+@pytest.mark.parametrize("geom_path", [0, 1, 2, 3])
+@pytest.mark.parametrize("scene,depth,rotat", [("sampleScene.txt", 6, 0), ("cornell_glass.txt", 10, 1),
+                                               ("cloud256.txt", 5, 1)])
+def test_every_geometry_path_against_oracle(pkg, geom_path, scene, depth, rotat):
+    g, lg, _ = gpu_render(pkg, scene, 192, 108, depth, iters=2, rotat=rotat, geom_path=geom_path, rr_start=3)
+    c, lc = cpu_render(scene, 192, 108, depth, iters=2, rotat=rotat, rr_start=3)
+    check(g, c, lg, lc, f"{scene} geom_path={geom_path}")
+
+
+@pytest.mark.parametrize("wg", [64, 256, 1024])
+def test_hit_queue_workgroup_sizes(pkg, wg):
+    ref, lr, _ = gpu_render(pkg, "sampleScene_spec.txt", 150, 100, 6, geom_path=1)
+    a, la, _ = gpu_render(pkg, "sampleScene_spec.txt", 150, 100, 6, geom_path=3, workgroup=wg)
+    b, lb, _ = gpu_render(pkg, "sampleScene_spec.txt", 150, 100, 6, geom_path=3, workgroup=wg, compaction=0)
+    assert np.array_equal(a, ref) and la == lr
+    assert np.array_equal(b, ref) and lb == lr
 
 
 def test_graph_vs_eager(pkg):

@@ -1,0 +1,298 @@
+"""Closed-form checks of the parts of the oracle that the reference ships as TODO stubs (no reference
+behaviour to pin to): box slab test, mirror law, Snell/TIR, Fresnel, camera rays, cosine-weighted sampling,
+Russian-roulette unbiasedness, energy conservation (furnace).  No GPU needed."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+
+def ray(o, d):
+    return O.Ray(O.v3(o), O.v3(d))
+
+
+def unit(v):
+    v = np.asarray(v, dtype=np.float64)
+    return (v / np.linalg.norm(v)).tolist()
+
+
+# ---------------------------------------------------------------- boxIntersectionTest (stub src/intersections.h:72-77)
+def box_hit(g, o, d):
+    p, n = O.Vec3(), O.Vec3()
+    t = O.lib().o_boxIntersectionTest(C.byref(g), ray(o, d), C.byref(p), C.byref(n))
+    return t, p.tup(), n.tup()
+
+
+def test_box_axis_aligned_front_face(oracle):
+    g = O.make_geom(O.CUBE, 0, (0, 0, 0), (0, 0, 0), (2, 2, 2))           # [-1,1]^3
+    t, p, n = box_hit(g, (0, 0, 5), (0, 0, -1))
+    assert abs(t - 4.0) < 3e-4 and abs(p[2] - 1.0) < 3e-4                  # 1e-4 object-space back-off x scale 2
+    assert n == (0.0, 0.0, 1.0)
+    assert abs(p[0]) < 1e-6 and abs(p[1]) < 1e-6
+
+
+def test_box_miss_and_behind(oracle):
+    g = O.make_geom(O.CUBE, 0, (0, 0, 0), (0, 0, 0), (2, 2, 2))
+    assert box_hit(g, (3, 0, 5), (0, 0, -1))[0] == -1.0                    # passes beside
+    assert box_hit(g, (0, 0, 5), (0, 0, 1))[0] == -1.0                     # box is behind the ray
+    assert box_hit(g, (0, 0, 5), unit((0, 1, -1)))[0] == -1.0              # over the top
+
+
+def test_box_from_inside_exit_face(oracle):
+    g = O.make_geom(O.CUBE, 0, (0, 0, 0), (0, 0, 0), (2, 4, 6))
+    t, p, n = box_hit(g, (0, 0, 0), (1, 0, 0))
+    assert abs(t - 1.0) < 3e-4 and n == (1.0, 0.0, 0.0)                    # exit face, normal along the ray
+    t, p, n = box_hit(g, (0, 0, 0), (0, -1, 0))
+    assert abs(t - 2.0) < 5e-4 and n == (0.0, -1.0, 0.0)
+    t, p, n = box_hit(g, (0.5, 0.5, 0), (0, 0, 1))
+    assert abs(t - 3.0) < 7e-4 and n == (0.0, 0.0, 1.0)
+
+
+def test_box_rotated_nonuniform_scale(oracle):
+    # rotate 90 deg about z (radians), scale (2,6,2): the long axis ends up along world x
+    g = O.make_geom(O.CUBE, 0, (1, 2, 3), (0, 0, math.pi / 2), (2, 6, 2))
+    t, p, n = box_hit(g, (10, 2, 3), (-1, 0, 0))
+    assert abs(p[0] - 4.0) < 1e-3 and abs(t - 6.0) < 1e-3
+    assert abs(n[0] - 1.0) < 1e-6 and abs(n[1]) < 1e-6 and abs(n[2]) < 1e-6
+    t, p, n = box_hit(g, (1, 10, 3), (0, -1, 0))
+    assert abs(p[1] - 3.0) < 1e-3 and abs(n[1] - 1.0) < 1e-6
+
+
+def test_box_grazing_and_axis_parallel(oracle):
+    g = O.make_geom(O.CUBE, 0, (0, 0, 0), (0, 0, 0), (2, 2, 2))
+    # ray parallel to two axes (object-space direction components exactly 0 -> slabs divide by zero)
+    t, p, n = box_hit(g, (0.25, -0.75, 9), (0, 0, -1))
+    assert abs(t - 8.0) < 3e-4 and n == (0.0, 0.0, 1.0)
+    # parallel ray outside the slab on x misses
+    assert box_hit(g, (1.5, 0, 9), (0, 0, -1))[0] == -1.0
+    # random rays: every reported hit point lies on the box surface, normal is a unit axis
+    rng = np.random.default_rng(1)
+    hits = 0
+    for _ in range(300):
+        o = rng.uniform(-4, 4, 3)
+        d = unit(rng.uniform(-1, 1, 3) - o)             # aim at the box so that most rays hit
+        t, p, n = box_hit(g, o.tolist(), d)
+        if t < 0:
+            continue
+        hits += 1
+        assert abs(max(abs(c) for c in p) - 1.0) < 2e-3
+        assert sorted(abs(c) for c in n)[:2] == [0.0, 0.0] and abs(max(abs(c) for c in n) - 1.0) < 1e-6
+        assert abs(np.linalg.norm(np.asarray(p) - o) - t) < 1e-5
+    assert hits > 30
+
+
+def test_sphere_box_consistency_on_same_ray(oracle):
+    """A ray through the common centre hits the inscribed sphere (r=.5*s) further in than the cube face."""
+    s = O.make_geom(O.SPHERE, 0, (0, 0, 0), (0, 0, 0), (2, 2, 2))
+    b = O.make_geom(O.CUBE, 0, (0, 0, 0), (0, 0, 0), (2, 2, 2))
+    p, n = O.Vec3(), O.Vec3()
+    ts = O.lib().o_sphereIntersectionTest(C.byref(s), ray((0, 0, 5), (0, 0, -1)), C.byref(p), C.byref(n))
+    tb = box_hit(b, (0, 0, 5), (0, 0, -1))[0]
+    assert abs(ts - 4.0) < 3e-4 and abs(tb - 4.0) < 3e-4
+    ts = O.lib().o_sphereIntersectionTest(C.byref(s), ray((5, 5, 5), unit((-1, -1, -1))), C.byref(p), C.byref(n))
+    tb = box_hit(b, (5, 5, 5), unit((-1, -1, -1)))[0]
+    assert ts > tb > 0
+
+
+# ---------------------------------------------------------------- reflection / refraction / Fresnel stubs
+def test_reflection_law(oracle):
+    L = oracle.lib()
+    r = L.o_calculateReflectionDirection(O.v3(0, 1, 0), O.v3(unit((1, -1, 0)))).tup()
+    np.testing.assert_allclose(r, unit((1, 1, 0)), atol=1e-7)
+    rng = np.random.default_rng(2)
+    for _ in range(50):
+        n, d = unit(rng.normal(size=3)), unit(rng.normal(size=3))
+        r = np.asarray(L.o_calculateReflectionDirection(O.v3(n), O.v3(d)).tup())
+        assert abs(np.linalg.norm(r) - 1) < 1e-6
+        assert abs(np.dot(r, n) + np.dot(d, n)) < 1e-6                 # angle in = angle out
+        np.testing.assert_allclose(np.cross(np.cross(d, n), np.cross(r, n)), 0, atol=1e-6)   # same plane
+
+
+def test_snell_and_total_internal_reflection(oracle):
+    L = oracle.lib()
+    n = (0, 1, 0)
+    for deg in (0, 10, 30, 60, 85):
+        th = math.radians(deg)
+        d = (math.sin(th), -math.cos(th), 0)
+        t = L.o_calculateTransmissionDirection(O.v3(n), O.v3(d), 1.0, 1.5).tup()
+        sin_t = math.hypot(t[0], t[2])
+        assert abs(sin_t - math.sin(th) / 1.5) < 1e-6                  # n1 sin(i) = n2 sin(t)
+        assert t[1] < 0 and abs(np.linalg.norm(t) - 1) < 1e-6
+    # glass -> air beyond the critical angle asin(1/1.5) = 41.8 deg
+    th = math.radians(45)
+    t = L.o_calculateTransmissionDirection(O.v3(n), O.v3((math.sin(th), -math.cos(th), 0)), 1.5, 1.0).tup()
+    assert t == (0.0, 0.0, 0.0)
+    th = math.radians(40)
+    t = L.o_calculateTransmissionDirection(O.v3(n), O.v3((math.sin(th), -math.cos(th), 0)), 1.5, 1.0).tup()
+    assert abs(math.hypot(t[0], t[2]) - 1.5 * math.sin(th)) < 1e-6
+
+
+def test_fresnel(oracle):
+    L = oracle.lib()
+    n, d = (0, 1, 0), (0, -1, 0)
+    for n1, n2 in ((1.0, 1.5), (1.0, 2.2), (1.5, 1.0), (1.33, 1.0)):
+        t = L.o_calculateTransmissionDirection(O.v3(n), O.v3(d), n1, n2)
+        f = L.o_calculateFresnel(O.v3(n), O.v3(d), n1, n2, O.v3(0, 1, 0), t)
+        want = ((n1 - n2) / (n1 + n2)) ** 2                             # normal incidence
+        assert abs(f.reflectionCoefficient - want) < 1e-6
+        assert abs(f.reflectionCoefficient + f.transmissionCoefficient - 1) < 1e-7
+    # grazing incidence -> reflectance -> 1 ; TIR -> exactly 1
+    th = math.radians(89.9)
+    d = (math.sin(th), -math.cos(th), 0)
+    t = L.o_calculateTransmissionDirection(O.v3(n), O.v3(d), 1.0, 1.5)
+    f = L.o_calculateFresnel(O.v3(n), O.v3(d), 1.0, 1.5, O.v3(0, 1, 0), t)
+    assert f.reflectionCoefficient > 0.98
+    f = L.o_calculateFresnel(O.v3(n), O.v3(d), 1.5, 1.0, O.v3(0, 1, 0), O.v3(0, 0, 0))
+    assert (f.reflectionCoefficient, f.transmissionCoefficient) == (1.0, 0.0)
+    # Brewster's angle: p-polarised reflectance vanishes -> R = rs^2 / 2
+    thb = math.atan(1.5)
+    d = (math.sin(thb), -math.cos(thb), 0)
+    t = L.o_calculateTransmissionDirection(O.v3(n), O.v3(d), 1.0, 1.5)
+    f = L.o_calculateFresnel(O.v3(n), O.v3(d), 1.0, 1.5, O.v3(0, 1, 0), t)
+    ci, ct = math.cos(thb), math.sqrt(1 - (math.sin(thb) / 1.5) ** 2)
+    rs = (ci - 1.5 * ct) / (ci + 1.5 * ct)
+    assert abs(f.reflectionCoefficient - 0.5 * rs * rs) < 1e-6
+
+
+def test_bsdf_lobe_selection(oracle):
+    L = oracle.lib()
+    n, p = O.v3(0, 1, 0), O.v3(0, 0, 0)
+    d = unit((1, -1, 0))
+    diffuse = O.make_material(color=(.2, .4, .6))
+    mirror = O.make_material(color=(.2, .4, .6), spec=(.9, .8, .7), refl=1.0)
+    glass = O.make_material(color=(0, 0, 0), spec=(1, 1, 1), refr=1.0, ior=1.5)
+    r = ray((0, 1, 0), d)
+    col = O.v3(1, 1, 1)
+    assert L.o_calculateBSDF(C.byref(r), p, n, C.byref(col), C.byref(diffuse), 0.5, 0.3, 0.7, O.TRIG_POLY) == 0
+    np.testing.assert_allclose(col.tup(), (.2, .4, .6), rtol=1e-7)
+    assert r.direction.y > 0 and abs(r.origin.y - 0.0002) < 1e-9            # leaves on the normal's side, biased
+    r, col = ray((0, 1, 0), d), O.v3(1, 1, 1)
+    assert L.o_calculateBSDF(C.byref(r), p, n, C.byref(col), C.byref(mirror), 0.5, 0.3, 0.7, O.TRIG_POLY) == 1
+    np.testing.assert_allclose(r.direction.tup(), unit((1, 1, 0)), atol=1e-7)
+    np.testing.assert_allclose(col.tup(), (.9, .8, .7), rtol=1e-7)
+    r, col = ray((0, 1, 0), d), O.v3(1, 1, 1)
+    assert L.o_calculateBSDF(C.byref(r), p, n, C.byref(col), C.byref(glass), 0.9999, 0.3, 0.7, O.TRIG_POLY) == 2
+    assert r.direction.y < 0 and r.origin.y < 0                              # transmitted, biased to the far side
+    r, col = ray((0, 1, 0), d), O.v3(1, 1, 1)
+    assert L.o_calculateBSDF(C.byref(r), p, n, C.byref(col), C.byref(glass), 0.0, 0.3, 0.7, O.TRIG_POLY) == 1
+    # hit from the back side: the shading normal flips, a diffuse bounce leaves on the ray's side
+    r, col = ray((0, -1, 0), (0, 1, 0)), O.v3(1, 1, 1)
+    L.o_calculateBSDF(C.byref(r), p, n, C.byref(col), C.byref(diffuse), 0.5, 0.3, 0.7, O.TRIG_POLY)
+    assert r.direction.y < 0 and r.origin.y < 0
+
+
+# ---------------------------------------------------------------- sampling
+def test_cosine_weighted_moments(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(3)
+    n = unit((0.3, 0.8, -0.5))
+    cos = []
+    for _ in range(20000):
+        v = L.o_calculateRandomDirectionInHemisphere(O.v3(n), float(rng.random()), float(rng.random()), O.TRIG_POLY).tup()
+        assert abs(np.linalg.norm(v) - 1) < 1e-5
+        cos.append(float(np.dot(v, n)))
+    cos = np.asarray(cos)
+    assert cos.min() >= -1e-6
+    assert abs(cos.mean() - 2.0 / 3.0) < 0.01          # E[cos] = 2/3 for p ~ cos
+    assert abs((cos ** 2).mean() - 0.5) < 0.01
+
+
+def test_uniform_sphere_direction(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(4)
+    v = np.array([L.o_getRandomDirectionInSphere(float(rng.random()), float(rng.random()), O.TRIG_POLY).tup()
+                  for _ in range(20000)])
+    np.testing.assert_allclose(np.linalg.norm(v, axis=1), 1, atol=1e-5)
+    assert np.abs(v.mean(axis=0)).max() < 0.02
+    assert abs((v[:, 2] ** 2).mean() - 1.0 / 3.0) < 0.01
+
+
+# ---------------------------------------------------------------- camera (stub src/raytraceKernel.cu:38-45)
+def test_camera_rays_span_the_fov(oracle):
+    L = oracle.lib()
+    W, H = 401, 301
+    cam = O.make_camera(W, H, (0, 4.5, 12), (0, 0, -1), (0, 1, 0), 25)
+
+    def mean_dir(x, y):
+        acc = np.zeros(3)
+        for it in range(1, 201):                       # average out the sub-pixel jitter
+            r = L.o_raycastFromCameraKernel(cam.resolution, float(it), x, y, cam.position, cam.view, cam.up, cam.fov, 0)
+            assert r.origin.tup() == (0.0, 4.5, 12.0)
+            acc += r.direction.tup()
+        return acc / np.linalg.norm(acc)
+
+    c = mean_dir(W // 2, H // 2)
+    np.testing.assert_allclose(c, (0, 0, -1), atol=2e-3)
+    top = mean_dir(W // 2, 0)                          # buffer y=0 is the top row
+    assert top[1] > 0 and abs(math.degrees(math.atan2(top[1], -top[2])) - 25) < 0.2
+    right_edge = mean_dir(0, H // 2)                   # buffer x=0 is screen-right (ref src/main.cpp:123 flips it back)
+    fovx = cam.fov.x
+    assert right_edge[0] > 0 and abs(math.degrees(math.atan2(right_edge[0], -right_edge[2])) - fovx) < 0.2
+
+
+def test_camera_jitter_stays_inside_the_pixel(oracle):
+    L = oracle.lib()
+    W, H = 64, 64
+    cam = O.make_camera(W, H, (0, 0, 0), (0, 0, -1), (0, 1, 0), 30)
+    ty = math.tan(math.radians(30))
+    for it in range(1, 100):
+        r = L.o_raycastFromCameraKernel(cam.resolution, float(it), 10, 20, cam.position, cam.view, cam.up, cam.fov, 0)
+        d = r.direction.tup()
+        sy = (1 - (d[1] / -d[2]) / ty) / 2 * H         # invert P = M + (1-2sx)H + (1-2sy)V
+        sx = (1 - (d[0] / -d[2]) / math.tan(math.radians(cam.fov.x))) / 2 * W
+        assert 20 - 1e-3 <= sy <= 21 + 1e-3 and 10 - 1e-3 <= sx <= 11 + 1e-3
+
+
+# ---------------------------------------------------------------- whole-path statistics
+def furnace_scene(emit, albedo):
+    """Camera inside a closed cube whose walls all emit `emit` and reflect `albedo` diffusely."""
+    geoms = (O.StaticGeom * 1)(O.make_geom(O.CUBE, 0, (0, 0, 0), (0, 0, 0), (10, 10, 10)))
+    mats = (O.Material * 1)(O.make_material(color=(albedo,) * 3, emittance=emit))
+    cam = O.make_camera(24, 24, (0, 0, 0), (0, 0, -1), (0, 1, 0), 30)
+    return geoms, mats, cam
+
+
+def test_emissive_enclosure_returns_emission(oracle):
+    geoms, mats, cam = furnace_scene(2.0, 0.5)
+    img, live = O.render(geoms, 1, mats, 1, cam, 4, iters=3)
+    np.testing.assert_allclose(img, 2.0 * 0.5, rtol=1e-6)      # every path hits a light first: L = T*color*emittance
+    assert [int(x) for x in live] == [3 * 24 * 24, 0, 0, 0]
+
+
+def test_russian_roulette_is_unbiased(oracle):
+    """Diffuse box lit by a ceiling light: means with and without roulette agree within noise."""
+    sc = O.LoadedScene(__import__("os").path.join(__import__("os").path.dirname(__file__), "..", "scenes", "sampleScene.txt"), 1)
+    sc.set_resolution(32, 32)
+    a, la = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, 12, iters=150, rr_start=-1)
+    b, lb = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, 12, iters=150, rr_start=2, seed=11)
+    assert lb.sum() < la.sum()
+    ma, mb = float(a.mean()), float(b.mean())
+    assert ma > 0.05
+    assert abs(ma - mb) / ma < 0.08
+
+
+def test_depth_limits_path_length(oracle):
+    sc = O.LoadedScene(__import__("os").path.join(__import__("os").path.dirname(__file__), "..", "scenes", "sampleScene.txt"))
+    sc.set_resolution(40, 40)
+    opt = O.Options(5, -1, 0, O.TRIG_POLY)
+    nb = C.c_int()
+    total = 0
+    for y in range(0, 40, 5):
+        for x in range(0, 40, 5):
+            O.lib().o_trace_path(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, C.byref(sc.camera), C.byref(opt), x, y, 1, C.byref(nb))
+            assert 1 <= nb.value <= 5
+            total += nb.value
+    assert total > 64
+
+
+def test_invalid_inputs_rejected(oracle):
+    geoms, mats, cam = furnace_scene(1.0, 0.5)
+    geoms[0].materialid = 3
+    with pytest.raises(RuntimeError):
+        O.render(geoms, 1, mats, 1, cam, 2)
+    geoms[0].materialid = 0
+    with pytest.raises(RuntimeError):
+        O.render(geoms, 1, mats, 1, cam, 0)

@@ -1,0 +1,85 @@
+"""N>1 path on CPU: world_size-2 (and 3) `gloo` processes shard a frame into row bands, render their band,
+gather to rank 0, and the result is bit-identical to the single-process frame.  The oracle plays the device
+here (tests may use it); the partition + gather code is the same module bench.py uses on RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as O
+from __graft_entry__ import load_package
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCENE = os.path.join(ROOT, "scenes", "sampleScene_spec.txt")
+W, H, DEPTH, ITERS = 96, 54, 4, 2
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def render_rows(r0, r1):
+    """Oracle render of rows [r0, r1) of the W x H frame: full-frame paths are keyed on the global pixel, so a
+    band is just a slice of the full image."""
+    sc = O.LoadedScene(SCENE)
+    sc.set_resolution(W, H)
+    img, live = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, DEPTH, iters=ITERS, nthreads=2)
+    return img[r0:r1].copy()
+
+
+def worker(rank, world, port, out_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = load_package()
+    from project3_pathtracer_amd import sharding
+    r0, r1 = sharding.band_rows(H, world, rank)
+    hmax = sharding.max_band_rows(H, world)
+    band = torch.zeros((hmax, W, 3), dtype=torch.float32)
+    band[: r1 - r0] = torch.from_numpy(render_rows(r0, r1))
+    frame = sharding.gather_bands(band, H, world, rank, dist=dist, dst=0)
+    if rank == 0:
+        np.save(out_path, frame.numpy())
+    else:
+        assert frame is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bands_gather_to_full_frame(world, tmp_path):
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(worker, args=(world, free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    want = render_rows(0, H)
+    assert got.shape == (H, W, 3)
+    assert np.array_equal(got, want)
+
+
+def test_band_partition_properties():
+    load_package()
+    from project3_pathtracer_amd import sharding
+    for h in (1, 7, 54, 1080, 2160, 3054):
+        for world in (1, 2, 3, 4, 8):
+            if world > h:
+                continue
+            rows = [sharding.band_rows(h, world, r) for r in range(world)]
+            assert rows[0][0] == 0 and rows[-1][1] == h
+            assert all(a[1] == b[0] for a, b in zip(rows, rows[1:]))          # no gap, no overlap
+            sizes = [b - a for a, b in rows]
+            assert max(sizes) - min(sizes) <= 1
+            assert sharding.max_band_rows(h, world) == max(sizes)
+    assert sharding.weak_scaled_frame(1920, 1080, 1) == (1920, 1080)
+    assert sharding.weak_scaled_frame(1920, 1080, 4) == (3840, 2160)          # BASELINE configs[3]
+    w8, h8 = sharding.weak_scaled_frame(1920, 1080, 8)
+    assert abs(w8 * h8 / (8 * 1920 * 1080) - 1) < 0.01
