@@ -148,6 +148,9 @@ int  pt_reset_stats(pt_ctx *ctx);
  * events on the render stream; bounce_ms_out[b] (depth entries) receives the summed duration of bounce b's
  * launches over the rendered iterations.  Synchronous.  For roofline accounting, not for throughput. */
 int  pt_render_profiled(pt_ctx *ctx, int iter_first, int iter_count, double *bounce_ms_out);
+/* Device self-test: the kernels' short correctly-rounded sqrt / reciprocal / reciprocal-sqrt sequences against
+ * the compiler's general ones for ALL 2^32 fp32 inputs.  mismatches_out[0..2] must come back 0. */
+int  pt_selftest_math(pt_ctx *ctx, unsigned long long mismatches_out[3]);
 
 /* ---- scene files (ref: src/scene.cpp, src/utilities.cpp:74-90; format README.md:160-217) ---- */
 enum { PT_ROTAT_RADIANS = 0,   /* what the reference binary does (GLM_FORCE_RADIANS, ref: src/utilities.cpp:7) */

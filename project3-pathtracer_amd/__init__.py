@@ -129,6 +129,7 @@ def lib():
         "pt_get_stats": (i, [vp, P(Stats)]),
         "pt_reset_stats": (i, [vp]),
         "pt_render_profiled": (i, [vp, i, i, P(C.c_double)]),
+        "pt_selftest_math": (i, [vp, P(C.c_ulonglong)]),
         "pt_scene_load": (i, [cp, i, P(vp)]),
         "pt_scene_free": (None, [vp]),
         "pt_scene_counts": (i, [vp, P(i), P(i), P(i)]),
@@ -266,6 +267,12 @@ class Renderer:
         ms = (C.c_double * PT_MAX_DEPTH)()
         _check(self.L.pt_render_profiled(self.h, iter_first, iter_count, ms), "pt_render_profiled")
         return [float(ms[b]) for b in range(self.opt.depth)]
+
+    def selftest_math(self):
+        """Mismatch counts of the kernels' exact sqrt / rcp / rsqrt sequences over all 2^32 inputs (must be 0)."""
+        out = (C.c_ulonglong * 3)()
+        _check(self.L.pt_selftest_math(self.h, out), "pt_selftest_math")
+        return [int(x) for x in out]
 
     def reset_stats(self):
         _check(self.L.pt_reset_stats(self.h), "pt_reset_stats")

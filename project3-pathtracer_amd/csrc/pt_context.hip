@@ -510,6 +510,21 @@ int pt_render_profiled(pt_ctx *c, int iter_first, int iter_count, double *bounce
     return PT_OK;
 }
 
+int pt_selftest_math(pt_ctx *c, unsigned long long mismatches_out[3])
+{
+    if (!c || !mismatches_out) return fail(PT_ERR_INVALID, "pt_selftest_math: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 3 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, 3 * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = pt::launch_selftest_math(c->stream, d);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(mismatches_out, d, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(PT_ERR_HIP, "pt_selftest_math: %s", hipGetErrorString(e));
+    return PT_OK;
+}
+
 int pt_send_image_to_pbo(pt_ctx *c, pt_uchar4 *device_pbo)
 {
     if (!c || !device_pbo) return fail(PT_ERR_INVALID, "pt_send_image_to_pbo: NULL argument");

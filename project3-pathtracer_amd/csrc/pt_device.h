@@ -30,10 +30,59 @@ __device__ __forceinline__ f3 cross(f3 x, f3 y)
 {
     return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
 }
-__device__ __forceinline__ float length(f3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
+// ---------------------------------------------------------------------------------------------
+// Correctly rounded sqrt and reciprocal, shorter than hipcc's general expansions.
+//
+// hipcc expands sqrtf(x) to 16 and 1.0f/x to 11 VALU instructions because it must also cover denormal
+// inputs/results, zero, inf and NaN.  Inside the usual range a v_sqrt_f32 / v_rcp_f32 seed plus the same
+// FMA corrections is already exactly rounded: checked against hipcc's results for ALL 2^32 inputs
+// (profiles/microbench/exact_math.hip, and pt_selftest_math() in every GPU test run):
+//   sqrt_core(x) == sqrtf(x)   for every x >= 2^-104, +inf and NaN      (used for x >= 2^-96)
+//   rcp_core(x)  == 1.0f / x   for every normal |x| < 2^126
+// Outside those ranges the wave falls back to the compiler's expansion.  The range test is made
+// wave-uniform with a ballot, so it costs one scalar branch and both sides stay straight-line code.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sqrt_core(float x)
+{
+    float y = __builtin_amdgcn_sqrtf(x);                               // <= 1 ulp
+    const float ym = __uint_as_float(__float_as_uint(y) - 1u), yp = __uint_as_float(__float_as_uint(y) + 1u);
+    const float rm = __builtin_fmaf(-ym, y, x), rp = __builtin_fmaf(-yp, y, x);   // exact residuals
+    y = (rm <= 0.0f) ? ym : y;
+    y = (rp > 0.0f) ? yp : y;
+    return y;
+}
+__device__ __forceinline__ float rcp_core(float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);                         // <= 1 ulp
+    const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e0, r0, r0);
+    const float e1 = __builtin_fmaf(-d, r1, 1.0f);
+    return __builtin_fmaf(e1, r1, r1);
+}
+__device__ __forceinline__ float sqrt_rn(float x)                      // == sqrtf(x) for every x
+{
+    const bool ok = x >= 0x1p-96f;                                     // false for tiny, zero, negative, NaN
+    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) return sqrt_core(x);
+    return sqrtf(x);
+}
+__device__ __forceinline__ float rcp_rn(float x)                       // == 1.0f / x for every x
+{
+    const float ax = fabsf(x);
+    const bool ok = ax >= 0x1p-126f && ax < 0x1p126f;
+    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) return rcp_core(x);
+    return 1.0f / x;
+}
+__device__ __forceinline__ float rsqrt_rn(float s)                     // == 1.0f / sqrtf(s) for every s
+{
+    const bool ok = s >= 0x1p-96f && s < 0x1p250f;                     // then sqrt(s) is in rcp_core's range
+    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) return rcp_core(sqrt_core(s));
+    return 1.0f / sqrtf(s);
+}
+
+__device__ __forceinline__ float length(f3 v) { return sqrt_rn(v.x * v.x + v.y * v.y + v.z * v.z); }
 __device__ __forceinline__ f3 normalize(f3 v)
 {
-    float inv = 1.0f / sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    float inv = rsqrt_rn(v.x * v.x + v.y * v.y + v.z * v.z);
     return mk(v.x * inv, v.y * inv, v.z * inv);
 }
 
@@ -143,7 +192,7 @@ __device__ __forceinline__ bool candidateT(uint32_t type, const float *inv, f3 o
         float vDot = dot(ro, rd);
         float radicand = (float)((double)(vDot * vDot) - ((double)dot(ro, ro) - 0.25));
         if (radicand < 0) return false;
-        float squareRoot = sqrtf(radicand);
+        float squareRoot = sqrt_rn(radicand);
         float firstTerm = -vDot;
         float t1 = firstTerm + squareRoot;
         float t2 = firstTerm - squareRoot;
@@ -153,14 +202,14 @@ __device__ __forceinline__ bool candidateT(uint32_t type, const float *inv, f3 o
         return true;
     }
     float inv1, t0, t1, tn, tf;
-    inv1 = 1.0f / rd.x; t0 = (-0.5f - ro.x) * inv1; t1 = (0.5f - ro.x) * inv1;
+    inv1 = rcp_rn(rd.x); t0 = (-0.5f - ro.x) * inv1; t1 = (0.5f - ro.x) * inv1;
     float tmin = (t0 < t1) ? t0 : t1, tmax = (t0 < t1) ? t1 : t0;
     int amin = 0, amax = 0;
-    inv1 = 1.0f / rd.y; t0 = (-0.5f - ro.y) * inv1; t1 = (0.5f - ro.y) * inv1;
+    inv1 = rcp_rn(rd.y); t0 = (-0.5f - ro.y) * inv1; t1 = (0.5f - ro.y) * inv1;
     tn = (t0 < t1) ? t0 : t1; tf = (t0 < t1) ? t1 : t0;
     if (tn > tmin) { tmin = tn; amin = 1; }
     if (tf < tmax) { tmax = tf; amax = 1; }
-    inv1 = 1.0f / rd.z; t0 = (-0.5f - ro.z) * inv1; t1 = (0.5f - ro.z) * inv1;
+    inv1 = rcp_rn(rd.z); t0 = (-0.5f - ro.z) * inv1; t1 = (0.5f - ro.z) * inv1;
     tn = (t0 < t1) ? t0 : t1; tf = (t0 < t1) ? t1 : t0;
     if (tn > tmin) { tmin = tn; amin = 2; }
     if (tf < tmax) { tmax = tf; amax = 2; }
@@ -208,8 +257,8 @@ __device__ __forceinline__ float intersectPrim(const Prim &g, f3 o, f3 d, f3 &po
 // calculateRandomDirectionInHemisphere (ref: src/interactions.h:62-87), deterministic trig
 __device__ __forceinline__ f3 randomDirectionInHemisphere(f3 normal, float xi1, float xi2)
 {
-    float up = sqrtf(xi1);
-    float over = sqrtf(1 - up * up);
+    float up = sqrt_rn(xi1);
+    float over = sqrt_rn(1 - up * up);
     float around = (float)((double)xi2 * 6.2831853071795864769252867665590057683943);
     f3 notNormal;
     if ((double)fabsf(normal.x) < 0.5773502691896257645091487805019574556476) notNormal = mk(1, 0, 0);
@@ -237,7 +286,7 @@ __device__ __forceinline__ f3 transmissionDirection(f3 normal, f3 incident, floa
     float sin2t = (eta * eta) * (1.0f - cosi * cosi);
     tir = sin2t > 1.0f;
     if (tir) return mk(0, 0, 0);
-    float cost = sqrtf(1.0f - sin2t);
+    float cost = sqrt_rn(1.0f - sin2t);
     float k = eta * cosi - cost;
     return (eta * incident) + (k * normal);
 }

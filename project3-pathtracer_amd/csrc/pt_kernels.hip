@@ -16,6 +16,8 @@
 // (global pixel, iteration, bounce).
 //
 // Compile with -ffp-contract=off (see pt_device.h).
+#include <stdlib.h>
+
 #include "pt_internal.h"
 
 namespace pt {
@@ -412,6 +414,34 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
 }
 
 // ---------------------------------------------------------------------------------------------
+// self-test of the short exact sqrt / reciprocal sequences (pt_device.h): every one of the 2^32 fp32 bit
+// patterns against hipcc's correctly rounded sqrtf(x), 1.0f/x and 1.0f/sqrtf(x).  out[0..2] = mismatch counts.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_selftest_math(unsigned long long *out)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    unsigned long long bad0 = 0, bad1 = 0, bad2 = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float x = __uint_as_float((uint32_t)i);
+        const float a = sqrtf(x), b = sqrt_rn(x);
+        if (__float_as_uint(a) != __float_as_uint(b) && !(a != a && b != b)) bad0++;
+        const float c = 1.0f / x, d = rcp_rn(x);
+        if (__float_as_uint(c) != __float_as_uint(d) && !(c != c && d != d)) bad1++;
+        const float e = 1.0f / sqrtf(x), f = rsqrt_rn(x);
+        if (__float_as_uint(e) != __float_as_uint(f) && !(e != e && f != f)) bad2++;
+    }
+    if (bad0) atomicAdd(&out[0], bad0);
+    if (bad1) atomicAdd(&out[1], bad1);
+    if (bad2) atomicAdd(&out[2], bad2);
+}
+
+hipError_t launch_selftest_math(hipStream_t s, unsigned long long *out)
+{
+    hipLaunchKernelGGL(k_selftest_math, dim3(256 * 8), dim3(256), 0, s, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // iteration bookkeeping
 // ---------------------------------------------------------------------------------------------
 __global__ void k_iter_set(IterState *st, uint32_t value) { st->iter = value; }
@@ -461,7 +491,8 @@ size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg)
     size_t queue = cfg.geom == GEOM_QUEUE ? (size_t)(cfg.workgroup / 64) * WAVE_QUEUE_BYTES : 0;
     size_t mats = (size_t)((p.nM * M_PLANES + 3) & ~3) * sizeof(float);
     size_t scan = (size_t)(2 * (cfg.workgroup / 64) + 2) * sizeof(uint32_t);
-    return prim + queue + mats + scan;
+    static const size_t extra = getenv("PT_EXTRA_LDS") ? (size_t)atol(getenv("PT_EXTRA_LDS")) : 0;   // occupancy experiments
+    return prim + queue + mats + scan + extra;
 }
 
 template <int WG, int GEOM, bool COMPACT>

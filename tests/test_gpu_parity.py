@@ -62,6 +62,13 @@ def check(gpu, cpu, live_g, live_c, what):
     assert np.isfinite(gpu).all()
 
 
+def test_exact_math_sequences_exhaustive(pkg):
+    """The kernels' short sqrt / 1/x / 1/sqrt sequences equal the compiler's correctly rounded ones for all
+    2^32 fp32 inputs (so replacing them cannot change a single bit of any image)."""
+    with pkg.Renderer(0) as r:
+        assert r.selftest_math() == [0, 0, 0]
+
+
 # ---------------------------------------------------------------- BASELINE config 1 and friends
 def test_config1_sample_scene_400x400_depth4(pkg):
     """BASELINE.json configs[0]: sampleScene.txt, 400x400, 1 spp, 4 bounces, fixed seed."""
