@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--workgroup", type=int, default=0)
     ap.add_argument("--geom-path", type=int, default=0)
     ap.add_argument("--no-compaction", action="store_true")
+    ap.add_argument("--compaction", type=int, default=1, help="1 per-wave sharded (default), 2 workgroup scan, 0 off")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
@@ -124,7 +125,7 @@ def main():
     fb = torch.zeros((Hmax, W, 3), dtype=torch.float32, device=dev)
     r = pkg.Renderer(local_rank)
     r.set_options(depth=args.depth, rr_start=args.rr_start, workgroup=args.workgroup, geom_path=args.geom_path,
-                  compaction=0 if args.no_compaction else 1, use_graph=0 if args.no_graph else 1,
+                  compaction=0 if args.no_compaction else args.compaction, use_graph=0 if args.no_graph else 1,
                   row_begin=r0 if world > 1 else 0, row_end=r1 if world > 1 else 0)
     r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
     r.set_camera(sc.camera)
@@ -207,7 +208,7 @@ def main():
                             f"{args.depth} bounces, diffuse+specular, rotat={args.rotat}, rr_start={args.rr_start}",
                 "scene": args.scene, "width": W, "height": Hfull, "depth": args.depth, "spp": args.steps,
                 "rotat_units": args.rotat, "primitives": sc.n_objects, "materials": sc.n_materials,
-                "compaction": not args.no_compaction, "hip_graph": not args.no_graph,
+                "compaction": 0 if args.no_compaction else args.compaction, "hip_graph": not args.no_graph,
                 "parallelism": f"pixel-bands x{world}" + (", 1 RCCL gather" if world > 1 else ""),
             },
             "ray_bounces": int(rb_total),

@@ -81,7 +81,8 @@ typedef struct pt_options {
     int depth;            /* bounces per path, 1..PT_MAX_DEPTH (default 8) */
     int rr_start;         /* first bounce with Russian roulette, <0 = off (default -1) */
     unsigned seed;        /* RNG stream selector (default 0) */
-    int compaction;       /* 1 = compact live rays after every bounce (default), 0 = rays keep their slot */
+    int compaction;       /* live-ray compaction after every bounce: 1 = per-wave reservation in 8 pool segments, no
+                             barrier (default); 2 = workgroup LDS scan + one counter; 0 = off, rays keep their slot */
     int workgroup;        /* threads per workgroup: 64, 128, 256, 512 or 1024 (default 0 = library choice) */
     int geom_path;        /* how primitives reach the lanes: 0 = library choice (default), 1 = scalar (SGPR) loads,
                              2 = staged in LDS, 3 = scalar candidate test + wave-private LDS hit queue */

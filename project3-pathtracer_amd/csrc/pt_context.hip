@@ -208,21 +208,6 @@ int configure(pt_ctx *c)
     }
     k.image = image_ptr(c);
 
-    // ray pools: 2 x npix x 40 B, carved from one allocation
-    const size_t npad = ((size_t)npix + 63) & ~(size_t)63;
-    const size_t one = npad * (16 + 16 + 8);
-    if (c->pool_cap < 2 * one) {
-        if (c->d_pool) (void)hipFree(c->d_pool);
-        c->d_pool = nullptr; c->pool_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_pool, 2 * one));
-        c->pool_cap = 2 * one;
-    }
-    for (int q = 0; q < 2; ++q) {
-        unsigned char *base = (unsigned char *)c->d_pool + (size_t)q * one;
-        k.pool[q].a = (float4 *)base;
-        k.pool[q].b = (float4 *)(base + npad * 16);
-        k.pool[q].c = (float2 *)(base + npad * 32);
-    }
     k.st = c->d_state;
 
     // launch shape: persistent workgroups, as many as are resident at once
@@ -230,7 +215,8 @@ int configure(pt_ctx *c)
     cfg.workgroup = o.workgroup ? o.workgroup : 256;
     // library choice: the hit queue pays when most primitives are hit by some lane of every wave (small scenes)
     cfg.geom = o.geom_path == 0 ? (k.nG <= 32 ? 2 : 0) : o.geom_path - 1;
-    cfg.compact = o.compaction != 0;
+    cfg.compact = o.compaction;
+    k.nshard = (cfg.compact == 1) ? pt::NSHARD : 1;
     const size_t lds = pt::bounce_lds_bytes(k, cfg);
     if (lds > 160 * 1024) return fail(PT_ERR_INVALID, "scene needs %zu B of LDS per workgroup (> 160 KiB)", lds);
     int per_cu = pt::bounce_max_blocks_per_cu(k, cfg);
@@ -241,6 +227,36 @@ int configure(pt_ctx *c)
     if (grid > want) grid = want;
     if (grid < 1) grid = 1;
     cfg.grid = (int)grid;
+
+    // ray pools: 2 x nshard segments of `segcap` rays x 40 B, carved from one allocation.  A segment must hold
+    // every survivor its writers can produce in one launch: each wave appends at most 64 rays per round and runs
+    // at most `rounds` rounds (chunks are 64 rays; per-segment padding adds at most NSHARD chunks).
+    {
+        const long long nw = cfg.workgroup / 64;
+        const long long total_waves = (long long)cfg.grid * nw;
+        const long long chunks = ((long long)npix + 63) / 64 + pt::NSHARD;
+        const long long rounds = (chunks + total_waves - 1) / total_waves;
+        long long writers = total_waves;                                   // nshard == 1: everyone writes segment 0
+        if (k.nshard > 1) writers = (total_waves + k.nshard - 1) / k.nshard;
+        long long segcap = writers * rounds * 64;
+        const long long npad = ((long long)npix + 63) & ~63LL;
+        if (k.nshard == 1 || segcap > npad) segcap = npad;                 // never more than all rays
+        k.segcap = (uint32_t)segcap;
+    }
+    const size_t slots = (size_t)k.segcap * (size_t)k.nshard;
+    const size_t one = slots * (16 + 16 + 8);
+    if (c->pool_cap < 2 * one) {
+        if (c->d_pool) (void)hipFree(c->d_pool);
+        c->d_pool = nullptr; c->pool_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_pool, 2 * one));
+        c->pool_cap = 2 * one;
+    }
+    for (int q = 0; q < 2; ++q) {
+        unsigned char *base = (unsigned char *)c->d_pool + (size_t)q * one;
+        k.pool[q].a = (float4 *)base;
+        k.pool[q].b = (float4 *)(base + slots * 16);
+        k.pool[q].c = (float2 *)(base + slots * 32);
+    }
 
     c->dirty = false;
     return PT_OK;
@@ -337,6 +353,7 @@ int pt_set_options(pt_ctx *c, const pt_options *o)
         return fail(PT_ERR_INVALID, "workgroup %d not one of 0,64,128,256,512,1024", wg);
     if (o->geom_path < 0 || o->geom_path > 3) return fail(PT_ERR_INVALID, "geom_path %d not in 0..3", o->geom_path);
     if (o->row_begin < 0 || o->row_end < o->row_begin) return fail(PT_ERR_INVALID, "tile rows [%d,%d)", o->row_begin, o->row_end);
+    if (o->compaction < 0 || o->compaction > 2) return fail(PT_ERR_INVALID, "compaction %d not 0, 1 or 2", o->compaction);
     c->opt = *o;
     c->dirty = true;
     return PT_OK;

@@ -21,11 +21,18 @@ struct RayPool {
 
 // Device-resident per-render state.  The iteration counter lives here (not in a kernel argument) so that
 // one captured hipGraph can be replayed for every iteration.
+// Live-ray counters are sharded: survivors of a bounce are appended to one of NSHARD dense pool segments, each
+// with its own reservation counter on its own 128-byte line, so that per-wave reservations do not all queue on
+// one address (one global counter saturates near 88 M atomics/s on this chip).
+static constexpr int NSHARD = 8;
+static constexpr int CNT_STRIDE = 32;            // uint32 per counter slot = 128 B
+__host__ __device__ constexpr int cnt_index(int bounce, int shard) { return (bounce * NSHARD + shard) * CNT_STRIDE; }
+
 struct IterState {
     uint32_t iter;                               // iteration being rendered (1-based, ref: src/main.cpp:95)
-    uint32_t pad[3];
-    uint32_t counts[PT_MAX_DEPTH + 1];           // live rays entering bounce b of this iteration
-    unsigned long long live_in[PT_MAX_DEPTH];    // the same, summed over iterations (stats)
+    uint32_t pad[31];
+    uint32_t counts[(PT_MAX_DEPTH + 1) * NSHARD * CNT_STRIDE];   // live rays entering bounce b, per segment
+    unsigned long long live_in[PT_MAX_DEPTH];    // summed over segments and iterations (stats)
     unsigned long long iterations;
 };
 
@@ -44,6 +51,8 @@ struct KParams {
     const ptd::Prim *prims;
     const float *mats;     // M_PLANES planes of nM floats
     float *image;          // tile framebuffer, fp32 RGB packed (12 B/pixel)
+    int nshard;            // pool segments in use: NSHARD (compaction 1), 1 otherwise
+    uint32_t segcap;       // slots per pool segment
     IterState *st;
     RayPool pool[2];
 };
@@ -52,12 +61,12 @@ struct LaunchCfg {
     int workgroup;   // 64..1024
     int grid;        // workgroups per bounce launch
     int geom;        // 0 scalar direct, 1 LDS direct, 2 hit queue (pt_kernels.hip)
-    bool compact;
+    int compact;     // 0 off, 1 per-wave sharded reservation, 2 workgroup scan + single counter
 };
 
 // kernels (pt_kernels.hip)
 hipError_t launch_iter_set(hipStream_t s, IterState *st, uint32_t value);
-hipError_t launch_iter_begin(hipStream_t s, IterState *st, int npix, int depth, bool compact);
+hipError_t launch_iter_begin(hipStream_t s, IterState *st, int npix, int depth, int compact);
 hipError_t launch_iter_fold(hipStream_t s, IterState *st, int depth);
 hipError_t launch_bounce(hipStream_t s, const KParams &p, const LaunchCfg &cfg, int bounce);
 hipError_t launch_send_image_to_pbo(hipStream_t s, pt_uchar4 *pbo, const float *image, int npix);

@@ -195,7 +195,9 @@ __device__ __forceinline__ Hit nearestHitQueued(const KParams &p, const Prim *s_
     return h;
 }
 
-template <int WG, bool FIRST, int GEOM, bool COMPACT>
+// COMPACT: 0 = rays keep their slot (validation / ablation), 1 = per-wave reservation on sharded counters
+// (no workgroup barrier), 2 = LDS scan over the workgroup's waves + one atomic per workgroup.
+template <int WG, bool FIRST, int GEOM, int COMPACT>
 __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce)
 {
     constexpr int NW = WG / 64;
@@ -233,7 +235,6 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
 
     IterState *st = p.st;
     const uint32_t iter = st->iter;
-    const uint32_t n = (FIRST || !COMPACT) ? (uint32_t)p.npix : st->counts[bounce];
     const RayPool in = p.pool[bounce & 1];
     const RayPool out = p.pool[(bounce + 1) & 1];
     const bool last = (bounce == p.depth - 1);
@@ -241,11 +242,38 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
     const uint32_t key_bounce = stream_key(iter, (uint32_t)bounce + 1u, p.seed);
     const float fi = (float)iter, fim1 = (float)(iter - 1u);
 
-    uint32_t live_count = 0;      // !COMPACT: rays this wave found alive on entry
+    // Input: the live rays of this bounce sit in up to NSHARD dense segments of the pool (one per reservation
+    // counter).  A wave works on 64-ray chunks; chunk -> (segment, offset) is wave-uniform scalar arithmetic.
+    uint32_t seg_n[NSHARD], seg_c0[NSHARD + 1];          // rays per segment, first chunk of each segment
+    seg_c0[0] = 0;
+#pragma unroll
+    for (int sh = 0; sh < NSHARD; ++sh) {
+        uint32_t ns = 0;
+        if (FIRST || COMPACT == 0) ns = (sh == 0) ? (uint32_t)p.npix : 0u;
+        else if (sh < p.nshard) ns = st->counts[cnt_index(bounce, sh)];
+        seg_n[sh] = ns;
+        seg_c0[sh + 1] = seg_c0[sh] + ((ns + 63u) >> 6);
+    }
+    const uint32_t total_chunks = seg_c0[NSHARD];
+    // the segment this wave (COMPACT 1) / workgroup (COMPACT 2) appends its survivors to
+    const uint32_t gwave = blockIdx.x * NW + wave;
+    const uint32_t myshard = (COMPACT == 1 ? gwave : blockIdx.x) & (uint32_t)(p.nshard - 1);
+    uint32_t *const out_counter = &st->counts[cnt_index(bounce + 1, myshard)];
+    const uint32_t out_base = myshard * p.segcap;
+
+    uint32_t live_count = 0;      // COMPACT 0: rays this wave found alive on entry
     int round = 0;
-    for (uint32_t base = blockIdx.x * WG; base < n; base += gridDim.x * WG, ++round) {
-        const uint32_t i = base + tid;
-        bool valid = i < n;
+    for (uint32_t R = blockIdx.x; R * NW < total_chunks; R += gridDim.x, ++round) {     // workgroup-uniform trip count
+        const uint32_t chunk = R * NW + wave;
+        uint32_t sh = 0;
+#pragma unroll
+        for (int k = 1; k < NSHARD; ++k) sh += (chunk >= seg_c0[k]) ? 1u : 0u;
+        uint32_t nseg = seg_n[0], c0 = 0;
+#pragma unroll
+        for (int k = 1; k < NSHARD; ++k) if (sh == (uint32_t)k) { nseg = seg_n[k]; c0 = seg_c0[k]; }
+        const uint32_t idx = (chunk - c0) * 64u + lane;          // index inside the segment
+        const uint32_t i = sh * p.segcap + idx;                   // pool slot (FIRST / COMPACT 0: sh == 0, i == idx)
+        bool valid = chunk < total_chunks && idx < nseg;
         f3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(1, 1, 1);
         uint32_t pix = 0;
         if (FIRST) {
@@ -272,7 +300,7 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
             if (valid) {
                 const float2 c = in.c[i];
                 pix = __float_as_uint(c.y);
-                if (!COMPACT && pix == DEAD) valid = false;
+                if (COMPACT == 0 && pix == DEAD) valid = false;
                 if (valid) {
                     const float4 a = in.a[i];
                     const float4 b = in.b[i];
@@ -282,7 +310,7 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
                 }
             }
         }
-        if (!COMPACT) live_count += (uint32_t)__popcll(__ballot(valid));
+        if (COMPACT == 0) live_count += (uint32_t)__popcll(__ballot(valid));
 
         bool alive = false;
         Hit h;
@@ -326,9 +354,9 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
                         const f3 rdir = reflectionDirection(nf, d);
                         bool tir;
                         const f3 tdir = transmissionDirection(nf, d, n1, n2, tir);
-                        const float R = fresnelReflectance(nf, d, n1, n2, tdir);
+                        const float Rf = fresnelReflectance(nf, d, n1, n2, tdir);
                         T = T * mk(s_mats[M_SR * p.nM + m], s_mats[M_SG * p.nM + m], s_mats[M_SB * p.nM + m]);
-                        if (u_select < R) nd = rdir;
+                        if (u_select < Rf) nd = rdir;
                         else { nd = tdir; bias_n = -nf; }
                     } else if (refl > 0.0f) {
                         T = T * mk(s_mats[M_SR * p.nM + m], s_mats[M_SG * p.nM + m], s_mats[M_SB * p.nM + m]);
@@ -362,16 +390,16 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
 
         if (last) continue;      // wave-uniform: nothing survives the last bounce
 
-        if (COMPACT) {
-            // stream compaction: wave ballot/mbcnt prefix -> LDS scan over waves -> one atomic per workgroup
+        if (COMPACT != 0) {
+            // stream compaction: wave ballot/mbcnt prefix, then a reservation in this wave's / workgroup's segment
             const uint64_t mask = __ballot(alive);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             const uint32_t wtot = (uint32_t)__popcll(mask);
             uint32_t dst;
-            if (NW == 1) {
+            if (COMPACT == 1 || NW == 1) {
                 uint32_t b = 0;
-                if (lane == 0 && wtot) b = atomicAdd(&st->counts[bounce + 1], wtot);
+                if (lane == 0 && wtot) b = atomicAdd(out_counter, wtot);
                 dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)b) + rank;
             } else {
                 const int par = round & 1;
@@ -383,13 +411,14 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
                     uint32_t sum = 0;
 #pragma unroll
                     for (int w = 0; w < NW; ++w) sum += tot[w];
-                    *gbase = sum ? atomicAdd(&st->counts[bounce + 1], sum) : 0u;
+                    *gbase = sum ? atomicAdd(out_counter, sum) : 0u;
                 }
                 __syncthreads();
                 uint32_t off = *gbase;
                 for (int w = 0; w < wave; ++w) off += tot[w];
                 dst = off + rank;
             }
+            dst += out_base;
             if (alive) {
                 out.a[dst] = make_float4(o.x, o.y, o.z, d.x);
                 out.b[dst] = make_float4(d.y, d.z, T.x, T.y);
@@ -397,7 +426,7 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
             }
         } else {
             // no compaction (validation / ablation mode): the ray keeps slot i, dead slots are tagged
-            if (i < n) {
+            if (chunk < total_chunks && idx < nseg) {
                 if (alive) {
                     out.a[i] = make_float4(o.x, o.y, o.z, d.x);
                     out.b[i] = make_float4(d.y, d.z, T.x, T.y);
@@ -408,8 +437,8 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
             }
         }
     }
-    if (!COMPACT) {
-        if (lane == 0 && live_count) atomicAdd(&st->counts[bounce], live_count);
+    if (COMPACT == 0) {
+        if (lane == 0 && live_count) atomicAdd(&st->counts[cnt_index(bounce, 0)], live_count);
     }
 }
 
@@ -450,18 +479,28 @@ __global__ void k_iter_set(IterState *st, uint32_t value) { st->iter = value; }
 __global__ void k_iter_begin(IterState *st, uint32_t npix, int depth, int compact)
 {
     const int b = threadIdx.x;
-    if (b < depth) st->live_in[b] += st->counts[b];
-    __syncthreads();
-    if (b <= depth) st->counts[b] = (b == 0 && compact) ? npix : 0u;
+    if (b <= depth) {
+        unsigned long long sum = 0;
+        for (int sh = 0; sh < NSHARD; ++sh) {
+            sum += st->counts[cnt_index(b, sh)];
+            st->counts[cnt_index(b, sh)] = (b == 0 && sh == 0 && compact) ? npix : 0u;
+        }
+        if (b < depth) st->live_in[b] += sum;
+    }
     if (b == 0) { st->iter += 1u; st->iterations += 1ull; }
 }
 
 __global__ void k_iter_fold(IterState *st, int depth)
 {
     const int b = threadIdx.x;
-    if (b < depth) st->live_in[b] += st->counts[b];
-    __syncthreads();
-    if (b <= depth) st->counts[b] = 0u;
+    if (b <= depth) {
+        unsigned long long sum = 0;
+        for (int sh = 0; sh < NSHARD; ++sh) {
+            sum += st->counts[cnt_index(b, sh)];
+            st->counts[cnt_index(b, sh)] = 0u;
+        }
+        if (b < depth) st->live_in[b] += sum;
+    }
 }
 
 // sendImageToPBO (ref: src/raytraceKernel.cu:58-89): x255 (the reference multiplies by the double 255.0 and
@@ -495,18 +534,26 @@ size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg)
     return prim + queue + mats + scan + extra;
 }
 
-template <int WG, int GEOM, bool COMPACT>
+template <int WG, int GEOM, int COMPACT>
 static const void *bounce_fn(bool first)
 {
     return first ? (const void *)k_bounce<WG, true, GEOM, COMPACT> : (const void *)k_bounce<WG, false, GEOM, COMPACT>;
 }
 
-template <int WG>
-static const void *bounce_fn_wg(bool first, int geom, bool compact)
+template <int WG, int GEOM>
+static const void *bounce_fn_geom(bool first, int compact)
 {
-    if (geom == GEOM_QUEUE) return compact ? bounce_fn<WG, GEOM_QUEUE, true>(first) : bounce_fn<WG, GEOM_QUEUE, false>(first);
-    if (geom == GEOM_LDS) return compact ? bounce_fn<WG, GEOM_LDS, true>(first) : bounce_fn<WG, GEOM_LDS, false>(first);
-    return compact ? bounce_fn<WG, GEOM_SCALAR, true>(first) : bounce_fn<WG, GEOM_SCALAR, false>(first);
+    if (compact == 1) return bounce_fn<WG, GEOM, 1>(first);
+    if (compact == 2) return bounce_fn<WG, GEOM, 2>(first);
+    return bounce_fn<WG, GEOM, 0>(first);
+}
+
+template <int WG>
+static const void *bounce_fn_wg(bool first, int geom, int compact)
+{
+    if (geom == GEOM_QUEUE) return bounce_fn_geom<WG, GEOM_QUEUE>(first, compact);
+    if (geom == GEOM_LDS) return bounce_fn_geom<WG, GEOM_LDS>(first, compact);
+    return bounce_fn_geom<WG, GEOM_SCALAR>(first, compact);
 }
 
 static const void *select_bounce(const LaunchCfg &cfg, bool first)
@@ -548,9 +595,9 @@ hipError_t launch_iter_set(hipStream_t s, IterState *st, uint32_t value)
     return hipGetLastError();
 }
 
-hipError_t launch_iter_begin(hipStream_t s, IterState *st, int npix, int depth, bool compact)
+hipError_t launch_iter_begin(hipStream_t s, IterState *st, int npix, int depth, int compact)
 {
-    hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(128), 0, s, st, (uint32_t)npix, depth, compact ? 1 : 0);
+    hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(128), 0, s, st, (uint32_t)npix, depth, compact != 0 ? 1 : 0);
     return hipGetLastError();
 }
 

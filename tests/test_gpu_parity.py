@@ -152,11 +152,21 @@ def test_render_iteration_reference_protocol(pkg):
 
 
 # ---------------------------------------------------------------- invariants of compaction / launch shape
-def test_compaction_on_off_identical(pkg):
+def test_compaction_modes_identical(pkg):
+    """per-wave sharded reservation (1), workgroup scan + one counter (2) and no compaction (0): same bits."""
     a, la, _ = gpu_render(pkg, "sampleScene_spec.txt", 200, 150, 6, compaction=1)
     b, lb, _ = gpu_render(pkg, "sampleScene_spec.txt", 200, 150, 6, compaction=0)
-    assert np.array_equal(a, b)
-    assert la == lb
+    c, lc, _ = gpu_render(pkg, "sampleScene_spec.txt", 200, 150, 6, compaction=2)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert la == lb == lc
+
+
+@pytest.mark.parametrize("compaction", [1, 2])
+@pytest.mark.parametrize("wg", [64, 256, 1024])
+def test_compaction_modes_against_oracle(pkg, compaction, wg):
+    g, lg, _ = gpu_render(pkg, "cornell_glass.txt", 231, 97, 9, iters=2, rotat=1, compaction=compaction, workgroup=wg)
+    c, lc = cpu_render("cornell_glass.txt", 231, 97, 9, iters=2, rotat=1)
+    check(g, c, lg, lc, f"compaction={compaction} wg={wg}")
 
 
 @pytest.mark.parametrize("wg", [64, 128, 256, 512, 1024])
