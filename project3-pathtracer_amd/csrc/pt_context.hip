@@ -7,6 +7,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -591,6 +592,9 @@ int pt_get_stats(pt_ctx *c, pt_stats *out)
     out->iterations = h.iterations;
     for (int b = 0; b < PT_MAX_DEPTH; ++b) { out->live_in[b] = h.live_in[b]; out->ray_bounces += h.live_in[b]; }
     out->gpu_ms = c->gpu_ms;
+    if (getenv("PT_DEBUG_CLOCK") && h.clk[1])
+        fprintf(stderr, "[ptamd] bounce-1 workgroup 0: %llu shader clocks in %llu x 10 ns -> %.0f MHz\n", h.clk[0], h.clk[1],
+                (double)h.clk[0] / (double)h.clk[1] * 100.0);
     out->bounce_launches = c->bounce_launches;
     return PT_OK;
 }

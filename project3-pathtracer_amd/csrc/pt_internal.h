@@ -34,6 +34,7 @@ struct IterState {
     uint32_t counts[(PT_MAX_DEPTH + 1) * NSHARD * CNT_STRIDE];   // live rays entering bounce b, per segment
     unsigned long long live_in[PT_MAX_DEPTH];    // summed over segments and iterations (stats)
     unsigned long long iterations;
+    unsigned long long clk[4];                   // diagnostics: shader-clock / real-time ticks spent by workgroup 0 of the last bounce-1 launch
 };
 
 struct KParams {

@@ -235,6 +235,8 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
 
     IterState *st = p.st;
     const uint32_t iter = st->iter;
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (bounce == 1 && blockIdx.x == 0 && tid == 0) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     const RayPool in = p.pool[bounce & 1];
     const RayPool out = p.pool[(bounce + 1) & 1];
     const bool last = (bounce == p.depth - 1);
@@ -439,6 +441,10 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
     }
     if (COMPACT == 0) {
         if (lane == 0 && live_count) atomicAdd(&st->counts[cnt_index(bounce, 0)], live_count);
+    }
+    if (bounce == 1 && blockIdx.x == 0 && tid == 0) {      // clock diagnostics (one thread per launch)
+        st->clk[0] = __builtin_amdgcn_s_memtime() - clk0;
+        st->clk[1] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
 }
 
