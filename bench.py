@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--workgroup", type=int, default=0)
     ap.add_argument("--geom-path", type=int, default=0)
     ap.add_argument("--no-compaction", action="store_true")
+    ap.add_argument("--batch", type=int, default=0, help="iterations in flight per launch sequence (0 = library default)")
     ap.add_argument("--compaction", type=int, default=1, help="1 per-wave sharded (default), 2 workgroup scan, 0 off")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -125,7 +126,7 @@ def main():
     fb = torch.zeros((Hmax, W, 3), dtype=torch.float32, device=dev)
     r = pkg.Renderer(local_rank)
     r.set_options(depth=args.depth, rr_start=args.rr_start, workgroup=args.workgroup, geom_path=args.geom_path,
-                  compaction=0 if args.no_compaction else args.compaction, use_graph=0 if args.no_graph else 1,
+                  compaction=0 if args.no_compaction else args.compaction, batch=args.batch, use_graph=0 if args.no_graph else 1,
                   row_begin=r0 if world > 1 else 0, row_end=r1 if world > 1 else 0)
     r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
     r.set_camera(sc.camera)
@@ -181,7 +182,7 @@ def main():
         p_live = [int(x) for x in pst.live_in[:args.depth]]
         p_bytes = pkg.algorithmic_bytes(npix, p_live, prof_steps)
         p_ms = sum(bounce_ms)
-        launches = prof_steps * args.depth
+        launches = int(pst.bounce_launches)      # one launch carries `batch` iterations of one bounce
         achieved = p_bytes / (p_ms * 1e-3) / 1e9
         traffic = None
         if os.path.exists(args.traffic_json):
@@ -208,7 +209,7 @@ def main():
                             f"{args.depth} bounces, diffuse+specular, rotat={args.rotat}, rr_start={args.rr_start}",
                 "scene": args.scene, "width": W, "height": Hfull, "depth": args.depth, "spp": args.steps,
                 "rotat_units": args.rotat, "primitives": sc.n_objects, "materials": sc.n_materials,
-                "compaction": 0 if args.no_compaction else args.compaction, "hip_graph": not args.no_graph,
+                "compaction": 0 if args.no_compaction else args.compaction, "iteration_batch": args.batch or 4, "hip_graph": not args.no_graph,
                 "parallelism": f"pixel-bands x{world}" + (", 1 RCCL gather" if world > 1 else ""),
             },
             "ray_bounces": int(rb_total),

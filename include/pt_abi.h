@@ -88,8 +88,11 @@ typedef struct pt_options {
                              2 = staged in LDS, 3 = scalar candidate test + wave-private LDS hit queue */
     int row_begin;        /* tile rendered by this context: rows [row_begin, row_end) of the frame; */
     int row_end;          /*   0,0 = the whole frame.  RNG streams are keyed on the global pixel index. */
-    int use_graph;        /* 1 = replay one captured hipGraph per iteration (default), 0 = eager launches */
-    int reserved[7];
+    int use_graph;        /* 1 = replay one captured hipGraph per launch sequence (default), 0 = eager launches */
+    int batch;            /* iterations rendered concurrently by one launch sequence, 1..4 (default 0 = library choice 4);
+                             their samples are folded into the running mean in iteration order, so the image does not
+                             depend on it */
+    int reserved[6];
 } pt_options;
 
 typedef struct pt_stats {

@@ -71,6 +71,9 @@ struct pt_ctx {
     size_t image_bytes = 0, image_cap = 0;
     void *d_pool = nullptr;
     size_t pool_cap = 0;
+    float *d_lbuf = nullptr;    // per-iteration radiance planes of the running batch
+    size_t lbuf_cap = 0;
+    int batch = 1;              // iterations in flight per launch sequence
     pt::IterState *d_state = nullptr;
     bool image_valid = false;   // framebuffer holds iterations 1..k of the current frame
 
@@ -223,11 +226,29 @@ int configure(pt_ctx *c)
     int per_cu = pt::bounce_max_blocks_per_cu(k, cfg);
     if (per_cu < 1) return fail(PT_ERR_HIP, "occupancy query failed for workgroup=%d (%s)", cfg.workgroup,
                                 hipGetErrorString(hipGetLastError()));
-    const long long want = ((long long)npix + cfg.workgroup - 1) / cfg.workgroup;
+    // iterations in flight per launch sequence: every bounce launch then carries batch x npix paths, which
+    // amortises the per-launch fixed cost (launch, LDS staging, ramp, tail) over `batch` samples per pixel
+    int batch = o.batch == 0 ? pt::PT_MAX_BATCH : o.batch;
+    while (batch > 1 && (long long)npix * batch > (1LL << 28)) --batch;
+    if (npix >= (1 << 28)) return fail(PT_ERR_INVALID, "tile of %d pixels too large (pixel index must fit 28 bits)", npix);
+    c->batch = batch;
+    k.nslot = batch;
+    const long long nrays = (long long)npix * batch;
+    const long long want = (nrays + cfg.workgroup - 1) / cfg.workgroup;
     long long grid = (long long)c->cu_count * per_cu;
     if (grid > want) grid = want;
     if (grid < 1) grid = 1;
     cfg.grid = (int)grid;
+
+    // per-iteration radiance planes (one write per path, folded into the image by k_accumulate)
+    const size_t lbuf_bytes = (size_t)nrays * 3 * sizeof(float);
+    if (c->lbuf_cap < lbuf_bytes) {
+        if (c->d_lbuf) (void)hipFree(c->d_lbuf);
+        c->d_lbuf = nullptr; c->lbuf_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c->d_lbuf, lbuf_bytes));
+        c->lbuf_cap = lbuf_bytes;
+    }
+    k.lbuf = c->d_lbuf;
 
     // ray pools: 2 x nshard segments of `segcap` rays x 40 B, carved from one allocation.  A segment must hold
     // every survivor its writers can produce in one launch: each wave appends at most 64 rays per round and runs
@@ -235,12 +256,12 @@ int configure(pt_ctx *c)
     {
         const long long nw = cfg.workgroup / 64;
         const long long total_waves = (long long)cfg.grid * nw;
-        const long long chunks = ((long long)npix + 63) / 64 + pt::NSHARD;
+        const long long chunks = (nrays + 63) / 64 + pt::NSHARD;
         const long long rounds = (chunks + total_waves - 1) / total_waves;
         long long writers = total_waves;                                   // nshard == 1: everyone writes segment 0
         if (k.nshard > 1) writers = (total_waves + k.nshard - 1) / k.nshard;
         long long segcap = writers * rounds * 64;
-        const long long npad = ((long long)npix + 63) & ~63LL;
+        const long long npad = (nrays + 63) & ~63LL;
         if (k.nshard == 1 || segcap > npad) segcap = npad;                 // never more than all rays
         k.segcap = (uint32_t)segcap;
     }
@@ -263,10 +284,19 @@ int configure(pt_ctx *c)
     return PT_OK;
 }
 
-int enqueue_iteration(pt_ctx *c, hipStream_t s)
+// one launch sequence = `nslot` consecutive iterations: bookkeeping, depth bounce launches, accumulate.
+// ev (optional): 2*depth events recorded around the bounce launches (pt_render_profiled).
+int enqueue_batch(pt_ctx *c, hipStream_t s, int nslot, hipEvent_t *ev)
 {
-    HIP_TRY(pt::launch_iter_begin(s, c->d_state, c->kp.npix, c->kp.depth, c->cfg.compact));
-    for (int b = 0; b < c->kp.depth; ++b) HIP_TRY(pt::launch_bounce(s, c->kp, c->cfg, b));
+    pt::KParams kp = c->kp;
+    kp.nslot = nslot;
+    HIP_TRY(pt::launch_iter_begin(s, c->d_state, (long long)kp.npix * nslot, kp.depth, c->cfg.compact, c->batch, nslot));
+    for (int b = 0; b < kp.depth; ++b) {
+        if (ev) HIP_TRY(hipEventRecord(ev[2 * b], s));
+        HIP_TRY(pt::launch_bounce(s, kp, c->cfg, b));
+        if (ev) HIP_TRY(hipEventRecord(ev[2 * b + 1], s));
+    }
+    HIP_TRY(pt::launch_accumulate(s, kp.image, kp.lbuf, c->d_state, kp.npix, nslot));
     return PT_OK;
 }
 
@@ -295,6 +325,7 @@ void pt_default_options(pt_options *o)
     o->workgroup = 0;
     o->geom_path = 0;
     o->use_graph = 1;
+    o->batch = 0;
 }
 
 int pt_create(int device, pt_ctx **out)
@@ -340,6 +371,7 @@ void pt_destroy(pt_ctx *c)
     if (c->d_mats) (void)hipFree(c->d_mats);
     if (c->d_image_own) (void)hipFree(c->d_image_own);
     if (c->d_pool) (void)hipFree(c->d_pool);
+    if (c->d_lbuf) (void)hipFree(c->d_lbuf);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -354,6 +386,7 @@ int pt_set_options(pt_ctx *c, const pt_options *o)
         return fail(PT_ERR_INVALID, "workgroup %d not one of 0,64,128,256,512,1024", wg);
     if (o->geom_path < 0 || o->geom_path > 3) return fail(PT_ERR_INVALID, "geom_path %d not in 0..3", o->geom_path);
     if (o->row_begin < 0 || o->row_end < o->row_begin) return fail(PT_ERR_INVALID, "tile rows [%d,%d)", o->row_begin, o->row_end);
+    if (o->batch < 0 || o->batch > pt::PT_MAX_BATCH) return fail(PT_ERR_INVALID, "batch %d not in 0..%d", o->batch, pt::PT_MAX_BATCH);
     if (o->compaction < 0 || o->compaction > 2) return fail(PT_ERR_INVALID, "compaction %d not 0, 1 or 2", o->compaction);
     c->opt = *o;
     c->dirty = true;
@@ -472,23 +505,27 @@ int pt_render(pt_ctx *c, int iter_first, int iter_count)
     c->timers.emplace_back(e0, e1);
     HIP_TRY(hipEventRecord(e0, s));
 
-    HIP_TRY(pt::launch_iter_set(s, c->d_state, (uint32_t)(iter_first - 1)));
-    if (c->opt.use_graph) {
+    // st->iter holds the first iteration of the running batch; every k_iter_begin advances it by one full batch
+    const int B = c->batch;
+    const int full = iter_count / B, rem = iter_count % B;
+    HIP_TRY(pt::launch_iter_set(s, c->d_state, (uint32_t)(iter_first - B)));
+    if (c->opt.use_graph && full > 0) {
         if (!c->graph_exec) {
             HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            rc = enqueue_iteration(c, s);
+            rc = enqueue_batch(c, s, B, nullptr);
             hipError_t ce = hipStreamEndCapture(s, &c->graph);
             if (rc != PT_OK) { drop_graph(c); return rc; }
             if (ce != hipSuccess) { drop_graph(c); return fail(PT_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce)); }
             HIP_TRY(hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
         }
-        for (int i = 0; i < iter_count; ++i) HIP_TRY(hipGraphLaunch(c->graph_exec, s));
+        for (int i = 0; i < full; ++i) HIP_TRY(hipGraphLaunch(c->graph_exec, s));
     } else {
-        for (int i = 0; i < iter_count; ++i) { rc = enqueue_iteration(c, s); if (rc != PT_OK) return rc; }
+        for (int i = 0; i < full; ++i) { rc = enqueue_batch(c, s, B, nullptr); if (rc != PT_OK) return rc; }
     }
+    if (rem > 0) { rc = enqueue_batch(c, s, rem, nullptr); if (rc != PT_OK) return rc; }
     HIP_TRY(pt::launch_iter_fold(s, c->d_state, c->kp.depth));
     HIP_TRY(hipEventRecord(e1, s));
-    c->bounce_launches += (unsigned long long)iter_count * (unsigned long long)c->kp.depth;
+    c->bounce_launches += (unsigned long long)(full + (rem ? 1 : 0)) * (unsigned long long)c->kp.depth;
     c->image_valid = true;
     return PT_OK;
 }
@@ -505,14 +542,14 @@ int pt_render_profiled(pt_ctx *c, int iter_first, int iter_count, double *bounce
     hipStream_t s = c->stream;
     std::vector<hipEvent_t> ev((size_t)2 * (size_t)depth);
     for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
-    HIP_TRY(pt::launch_iter_set(s, c->d_state, (uint32_t)(iter_first - 1)));
-    for (int i = 0; i < iter_count; ++i) {
-        HIP_TRY(pt::launch_iter_begin(s, c->d_state, c->kp.npix, depth, c->cfg.compact));
-        for (int b = 0; b < depth; ++b) {
-            HIP_TRY(hipEventRecord(ev[2 * b], s));
-            HIP_TRY(pt::launch_bounce(s, c->kp, c->cfg, b));
-            HIP_TRY(hipEventRecord(ev[2 * b + 1], s));
-        }
+    const int B = c->batch;
+    HIP_TRY(pt::launch_iter_set(s, c->d_state, (uint32_t)(iter_first - B)));
+    int launches = 0;
+    for (int done = 0; done < iter_count; done += B) {
+        const int nslot = (iter_count - done) < B ? (iter_count - done) : B;
+        rc = enqueue_batch(c, s, nslot, ev.data());
+        if (rc != PT_OK) return rc;
+        launches++;
         HIP_TRY(hipStreamSynchronize(s));
         for (int b = 0; b < depth; ++b) {
             float ms = 0.0f;
@@ -523,7 +560,7 @@ int pt_render_profiled(pt_ctx *c, int iter_first, int iter_count, double *bounce
     HIP_TRY(pt::launch_iter_fold(s, c->d_state, depth));
     HIP_TRY(hipStreamSynchronize(s));
     for (auto &e : ev) (void)hipEventDestroy(e);
-    c->bounce_launches += (unsigned long long)iter_count * (unsigned long long)depth;
+    c->bounce_launches += (unsigned long long)launches * (unsigned long long)depth;
     c->image_valid = true;
     return PT_OK;
 }

@@ -25,6 +25,7 @@ struct RayPool {
 // with its own reservation counter on its own 128-byte line, so that per-wave reservations do not all queue on
 // one address (one global counter saturates near 88 M atomics/s on this chip).
 static constexpr int NSHARD = 8;
+static constexpr int PT_MAX_BATCH = 4;          // iterations rendered concurrently by one launch sequence
 static constexpr int CNT_STRIDE = 32;            // uint32 per counter slot = 128 B
 __host__ __device__ constexpr int cnt_index(int bounce, int shard) { return (bounce * NSHARD + shard) * CNT_STRIDE; }
 
@@ -52,6 +53,8 @@ struct KParams {
     const ptd::Prim *prims;
     const float *mats;     // M_PLANES planes of nM floats
     float *image;          // tile framebuffer, fp32 RGB packed (12 B/pixel)
+    int nslot;             // iterations in flight in this launch sequence (1..PT_MAX_BATCH)
+    float *lbuf;           // nslot planes of npix fp32 RGB radiance samples, folded into `image` by k_accumulate
     int nshard;            // pool segments in use: NSHARD (compaction 1), 1 otherwise
     uint32_t segcap;       // slots per pool segment
     IterState *st;
@@ -67,7 +70,8 @@ struct LaunchCfg {
 
 // kernels (pt_kernels.hip)
 hipError_t launch_iter_set(hipStream_t s, IterState *st, uint32_t value);
-hipError_t launch_iter_begin(hipStream_t s, IterState *st, int npix, int depth, int compact);
+hipError_t launch_iter_begin(hipStream_t s, IterState *st, long long nrays, int depth, int compact, int step, int nslot);
+hipError_t launch_accumulate(hipStream_t s, float *image, const float *lbuf, const IterState *st, int npix, int nslot);
 hipError_t launch_iter_fold(hipStream_t s, IterState *st, int depth);
 hipError_t launch_bounce(hipStream_t s, const KParams &p, const LaunchCfg &cfg, int bounce);
 hipError_t launch_send_image_to_pbo(hipStream_t s, pt_uchar4 *pbo, const float *image, int npix);

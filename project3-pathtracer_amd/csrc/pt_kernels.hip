@@ -24,6 +24,9 @@ namespace pt {
 using namespace ptd;
 
 static constexpr uint32_t DEAD = 0xFFFFFFFFu;
+static constexpr int MAXSLOT = 4;                 // iterations in flight per launch sequence (pt_internal.h PT_MAX_BATCH)
+static constexpr uint32_t SLOT_SHIFT = 28;        // pixel word = tile-local pixel | slot << 28
+static constexpr uint32_t PIX_MASK = (1u << SLOT_SHIFT) - 1u;
 
 typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
 
@@ -240,9 +243,15 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
     const RayPool in = p.pool[bounce & 1];
     const RayPool out = p.pool[(bounce + 1) & 1];
     const bool last = (bounce == p.depth - 1);
-    const uint32_t key_cam = stream_key(iter, 0u, p.seed);
-    const uint32_t key_bounce = stream_key(iter, (uint32_t)bounce + 1u, p.seed);
-    const float fi = (float)iter, fim1 = (float)(iter - 1u);
+    // Up to MAXSLOT consecutive iterations are in flight in one launch sequence; a ray carries its iteration
+    // slot in the top bits of its pixel word.  The per-(iteration, bounce) stream keys are wave-uniform.
+    uint32_t key_cam[MAXSLOT], key_bounce[MAXSLOT];
+#pragma unroll
+    for (int k = 0; k < MAXSLOT; ++k) {
+        key_cam[k] = stream_key(iter + (uint32_t)k, 0u, p.seed);
+        key_bounce[k] = stream_key(iter + (uint32_t)k, (uint32_t)bounce + 1u, p.seed);
+    }
+    const uint32_t npix = (uint32_t)p.npix;
 
     // Input: the live rays of this bounce sit in up to NSHARD dense segments of the pool (one per reservation
     // counter).  A wave works on 64-ray chunks; chunk -> (segment, offset) is wave-uniform scalar arithmetic.
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
 #pragma unroll
     for (int sh = 0; sh < NSHARD; ++sh) {
         uint32_t ns = 0;
-        if (FIRST || COMPACT == 0) ns = (sh == 0) ? (uint32_t)p.npix : 0u;
+        if (FIRST || COMPACT == 0) ns = (sh == 0) ? (uint32_t)p.npix * (uint32_t)p.nslot : 0u;
         else if (sh < p.nshard) ns = st->counts[cnt_index(bounce, sh)];
         seg_n[sh] = ns;
         seg_c0[sh + 1] = seg_c0[sh] + ((ns + 63u) >> 6);
@@ -280,12 +289,15 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
         uint32_t pix = 0;
         if (FIRST) {
             if (valid) {
-                // raycastFromCameraKernel: jittered pinhole ray through tile-local pixel i
-                pix = i;
-                const uint32_t gp = pix + p.pix_offset;
-                const uint32_t x = i % (uint32_t)p.W;
-                const uint32_t y = (uint32_t)p.row_begin + i / (uint32_t)p.W;
-                uint32_t s = minstd_seed(wang_hash(gp ^ key_cam));
+                // raycastFromCameraKernel: jittered pinhole ray through tile-local pixel pl of iteration slot
+                const uint32_t slot = (i >= npix ? 1u : 0u) + (i >= 2u * npix ? 1u : 0u) + (i >= 3u * npix ? 1u : 0u);
+                const uint32_t pl = i - slot * npix;
+                pix = pl | (slot << SLOT_SHIFT);
+                const uint32_t gp = pl + p.pix_offset;
+                const uint32_t x = pl % (uint32_t)p.W;
+                const uint32_t y = (uint32_t)p.row_begin + pl / (uint32_t)p.W;
+                const uint32_t kc = slot == 0u ? key_cam[0] : slot == 1u ? key_cam[1] : slot == 2u ? key_cam[2] : key_cam[3];
+                uint32_t s = minstd_seed(wang_hash(gp ^ kc));
                 s = minstd_next(s);
                 const float jx = u01_of(s);
                 s = minstd_next(s);
@@ -332,7 +344,9 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
                     L = emit * (T * col);
                 } else if (!last) {
                     // calculateBSDF: pick the lobe, build the next ray
-                    uint32_t s = minstd_seed(wang_hash((pix + p.pix_offset) ^ key_bounce));
+                    const uint32_t slot = pix >> SLOT_SHIFT;
+                    const uint32_t kb = slot == 0u ? key_bounce[0] : slot == 1u ? key_bounce[1] : slot == 2u ? key_bounce[2] : key_bounce[3];
+                    uint32_t s = minstd_seed(wang_hash(((pix & PIX_MASK) + p.pix_offset) ^ kb));
                     s = minstd_next(s);
                     const float u_select = u01_of(s);
                     s = minstd_next(s);
@@ -381,12 +395,12 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
                 }
             }
             if (!alive) {
-                // the path ends here: its single read-modify-write of the pixel's running mean
-                float *px = p.image + 3u * (size_t)pix;
-                const float r0 = px[0], r1 = px[1], r2 = px[2];
-                px[0] = (r0 * fim1 + L.x) / fi;
-                px[1] = (r1 * fim1 + L.y) / fi;
-                px[2] = (r2 * fim1 + L.z) / fi;
+                // the path ends here: its radiance sample goes to this iteration slot's plane; k_accumulate folds
+                // the planes into the running mean in iteration order once the launch sequence is done
+                float *lp = p.lbuf + 3u * ((size_t)(pix >> SLOT_SHIFT) * npix + (size_t)(pix & PIX_MASK));
+                lp[0] = L.x;
+                lp[1] = L.y;
+                lp[2] = L.z;
             }
         }
 
@@ -482,18 +496,40 @@ hipError_t launch_selftest_math(hipStream_t s, unsigned long long *out)
 __global__ void k_iter_set(IterState *st, uint32_t value) { st->iter = value; }
 
 // fold the previous iteration's per-bounce live counts into the stats, reset them, advance the iteration
-__global__ void k_iter_begin(IterState *st, uint32_t npix, int depth, int compact)
+// starts a batch of `nslot` iterations: fold the previous batch's counters, reset them, advance the iteration
+// counter by `step` (the size of the previous batch; st->iter is the first iteration of the current batch)
+__global__ void k_iter_begin(IterState *st, uint32_t nrays, int depth, int compact, uint32_t step, uint32_t nslot)
 {
     const int b = threadIdx.x;
     if (b <= depth) {
         unsigned long long sum = 0;
         for (int sh = 0; sh < NSHARD; ++sh) {
             sum += st->counts[cnt_index(b, sh)];
-            st->counts[cnt_index(b, sh)] = (b == 0 && sh == 0 && compact) ? npix : 0u;
+            st->counts[cnt_index(b, sh)] = (b == 0 && sh == 0 && compact) ? nrays : 0u;
         }
         if (b < depth) st->live_in[b] += sum;
     }
-    if (b == 0) { st->iter += 1u; st->iterations += 1ull; }
+    if (b == 0) { st->iter += step; st->iterations += nslot; }
+}
+
+// Accumulation (DESIGN.md "Canonical semantics" 6): image = (image*(i-1) + L_i)/i for the batch's iterations in
+// order, one thread per pixel, streaming (the per-path samples were written to lbuf by k_bounce).
+__global__ __launch_bounds__(256) void k_accumulate(float *image, const float *lbuf, const IterState *st, int npix, int nslot)
+{
+    const uint32_t iter0 = st->iter;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+        float r = image[3 * i], g = image[3 * i + 1], b = image[3 * i + 2];
+        for (int k = 0; k < nslot; ++k) {
+            const float *lp = lbuf + 3 * ((size_t)k * (size_t)npix + (size_t)i);
+            const float fi = (float)(iter0 + (uint32_t)k), fim1 = (float)(iter0 + (uint32_t)k - 1u);
+            r = (r * fim1 + lp[0]) / fi;
+            g = (g * fim1 + lp[1]) / fi;
+            b = (b * fim1 + lp[2]) / fi;
+        }
+        image[3 * i] = r;
+        image[3 * i + 1] = g;
+        image[3 * i + 2] = b;
+    }
 }
 
 __global__ void k_iter_fold(IterState *st, int depth)
@@ -601,9 +637,19 @@ hipError_t launch_iter_set(hipStream_t s, IterState *st, uint32_t value)
     return hipGetLastError();
 }
 
-hipError_t launch_iter_begin(hipStream_t s, IterState *st, int npix, int depth, int compact)
+hipError_t launch_iter_begin(hipStream_t s, IterState *st, long long nrays, int depth, int compact, int step, int nslot)
 {
-    hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(128), 0, s, st, (uint32_t)npix, depth, compact != 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(128), 0, s, st, (uint32_t)nrays, depth, compact != 0 ? 1 : 0,
+                       (uint32_t)step, (uint32_t)nslot);
+    return hipGetLastError();
+}
+
+hipError_t launch_accumulate(hipStream_t s, float *image, const float *lbuf, const IterState *st, int npix, int nslot)
+{
+    int grid = (npix + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(256), 0, s, image, lbuf, st, npix, nslot);
     return hipGetLastError();
 }
 

@@ -127,6 +127,16 @@ def test_multi_iteration_running_mean(pkg):
     assert st.iterations == 6
 
 
+@pytest.mark.parametrize("batch", [1, 2, 3, 4])
+def test_iteration_batching_is_invisible(pkg, batch):
+    """1..4 iterations in flight per launch sequence; samples are folded in iteration order, so the running
+    mean is the same bits, also when the iteration count is not a multiple of the batch."""
+    g, lg, st = gpu_render(pkg, "sampleScene_spec.txt", 121, 67, 5, iters=7, batch=batch, rr_start=2)
+    c, lc = cpu_render("sampleScene_spec.txt", 121, 67, 5, iters=7, rr_start=2)
+    check(g, c, lg, lc, f"batch={batch}")
+    assert st.iterations == 7
+
+
 def test_resume_from_host_image(pkg):
     """(image, iteration) is a complete state: 1..3 then 4..6 from the downloaded image == 1..6."""
     full, lf, _ = gpu_render(pkg, "sampleScene.txt", 96, 64, 4, iters=6)
