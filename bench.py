@@ -105,11 +105,18 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the render path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal mode for a 1-GPU box: all ranks share device 0 and the collective runs on gloo (RCCL refuses two
+    # ranks on one device); the driver's real runs use one GPU per rank and nccl (= RCCL over xGMI)
+    rehearsal = os.environ.get("PT_BENCH_REHEARSAL", "0") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     rotat = pkg.ROTAT_DEGREES if args.rotat == "degrees" else pkg.ROTAT_RADIANS
     scene_path = os.path.join(ROOT, "scenes", args.scene)
@@ -124,7 +131,7 @@ def main():
     Hmax = sharding.max_band_rows(Hfull, world)
 
     fb = torch.zeros((Hmax, W, 3), dtype=torch.float32, device=dev)
-    r = pkg.Renderer(local_rank)
+    r = pkg.Renderer(dev_index)
     r.set_options(depth=args.depth, rr_start=args.rr_start, workgroup=args.workgroup, geom_path=args.geom_path,
                   compaction=0 if args.no_compaction else args.compaction, batch=args.batch, use_graph=0 if args.no_graph else 1,
                   row_begin=r0 if world > 1 else 0, row_end=r1 if world > 1 else 0)
@@ -132,18 +139,30 @@ def main():
     r.set_camera(sc.camera)
     r.bind_image(fb.data_ptr())
 
+    def barrier():
+        if rehearsal:
+            dist.barrier()
+        else:
+            dist.barrier(device_ids=[dev_index])
+
+    def gather():
+        if rehearsal:      # gloo moves host tensors
+            host = sharding.gather_bands(fb.cpu(), Hfull, world, rank, dist=dist, dst=0)
+            return host
+        return sharding.gather_bands(fb, Hfull, world, rank, dist=dist, dst=0)       # RCCL over xGMI
+
     def sync():
         r.synchronize()
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            barrier()
             torch.cuda.synchronize(dev)
 
     # warmup (untimed): also captures the per-iteration hipGraph
     if args.warmup > 0:
         r.render(1, args.warmup)
     if world > 1:
-        frame = sharding.gather_bands(fb, Hfull, world, rank, dist=dist, dst=0)   # RCCL over xGMI
+        frame = gather()
     sync()
     r.reset_stats()
 
@@ -154,14 +173,14 @@ def main():
     r.render(first, args.steps)
     r.synchronize()
     if world > 1:
-        frame = sharding.gather_bands(fb, Hfull, world, rank, dist=dist, dst=0)   # RCCL over xGMI
+        frame = gather()
     sync()
     dt = time.perf_counter() - t0
 
     st = r.stats()
     rb_local = int(st.ray_bounces)
     live_in = [int(x) for x in st.live_in[:args.depth]]
-    tens = torch.tensor([dt, float(rb_local), float(st.gpu_ms)], dtype=torch.float64, device=dev)
+    tens = torch.tensor([dt, float(rb_local), float(st.gpu_ms)], dtype=torch.float64, device="cpu" if rehearsal else dev)
     if world > 1:
         tmax = tens.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -242,7 +261,7 @@ def main():
 
     r.close()
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
 
 
