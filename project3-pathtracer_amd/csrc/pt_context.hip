@@ -176,6 +176,27 @@ int configure(pt_ctx *c)
             p.cx = (m.x.x * 0.0f) + (m.x.y * 0.0f) + (m.x.z * 0.0f) + (m.x.w * 1.0f);
             p.cy = (m.y.x * 0.0f) + (m.y.y * 0.0f) + (m.y.z * 0.0f) + (m.y.w * 1.0f);
             p.cz = (m.z.x * 0.0f) + (m.z.y * 0.0f) + (m.z.z * 0.0f) + (m.z.w * 1.0f);
+            // padded bounding sphere: every point of the unit cube / r=.5 sphere lies within half the sum of the
+            // transform's column lengths of the centre; +2 % and +1e-3 absorb fp32 rounding of the cull test
+            double len[3], colv[3][3], sum = 0.0, sumsq = 0.0, maxlen = 0.0;
+            for (int col = 0; col < 3; ++col) {
+                const float *r0 = &m.x.x, *r1 = &m.y.x, *r2 = &m.z.x;
+                colv[col][0] = r0[col]; colv[col][1] = r1[col]; colv[col][2] = r2[col];
+                len[col] = sqrt(colv[col][0] * colv[col][0] + colv[col][1] * colv[col][1] + colv[col][2] * colv[col][2]);
+                sum += len[col]; sumsq += len[col] * len[col];
+                if (len[col] > maxlen) maxlen = len[col];
+            }
+            bool orthogonal = true;                       // T*R*S transforms have orthogonal columns
+            for (int a = 0; a < 3; ++a)
+                for (int b = a + 1; b < 3; ++b) {
+                    const double dp = colv[a][0] * colv[b][0] + colv[a][1] * colv[b][1] + colv[a][2] * colv[b][2];
+                    if (fabs(dp) > 1e-4 * len[a] * len[b]) orthogonal = false;
+                }
+            double rad;
+            if (orthogonal) rad = (g.type == PT_SPHERE) ? 0.5 * maxlen : 0.5 * sqrt(sumsq);   // r*s_max / half diagonal
+            else rad = (g.type == PT_SPHERE) ? 0.5 * sqrt(sumsq) : 0.5 * sum;                  // Frobenius / triangle bound
+            rad = rad * 1.02 + 1e-3;
+            p.bound_r2 = (float)(rad * rad);
         }
         if (c->d_prims) { (void)hipFree(c->d_prims); c->d_prims = nullptr; }
         HIP_TRY(hipMalloc((void **)&c->d_prims, prims.size() * sizeof(ptd::Prim)));
@@ -220,6 +241,7 @@ int configure(pt_ctx *c)
     // library choice: the hit queue pays when most primitives are hit by some lane of every wave (small scenes)
     cfg.geom = o.geom_path == 0 ? (k.nG <= 32 ? 2 : 0) : o.geom_path - 1;
     cfg.compact = o.compaction;
+    k.cull = (k.nG > 32 && !getenv("PT_NO_CULL")) ? 1 : 0;
     k.nshard = (cfg.compact == 1) ? pt::NSHARD : 1;
     const size_t lds = pt::bounce_lds_bytes(k, cfg);
     if (lds > 160 * 1024) return fail(PT_ERR_INVALID, "scene needs %zu B of LDS per workgroup (> 160 KiB)", lds);
@@ -629,6 +651,7 @@ int pt_get_stats(pt_ctx *c, pt_stats *out)
     out->iterations = h.iterations;
     for (int b = 0; b < PT_MAX_DEPTH; ++b) { out->live_in[b] = h.live_in[b]; out->ray_bounces += h.live_in[b]; }
     out->gpu_ms = c->gpu_ms;
+    if (getenv("PT_DEBUG_CLOCK")) fprintf(stderr, "[ptamd] cull: tested %llu skipped %llu (wave x primitive)\n", h.clk[2], h.clk[3]);
     if (getenv("PT_DEBUG_CLOCK") && h.clk[1])
         fprintf(stderr, "[ptamd] bounce-1 workgroup 0: %llu shader clocks in %llu x 10 ns -> %.0f MHz\n", h.clk[0], h.clk[1],
                 (double)h.clk[0] / (double)h.clk[1] * 100.0);

@@ -98,7 +98,7 @@ struct Prim {
     float inv[12];       // inverseTransform rows x,y,z (x y z w each)
     float fwd[12];       // transform rows x,y,z
     float cx, cy, cz;    // transform * (0,0,0,1), evaluated on the host with multiplyMV's operation order
-    uint32_t pad2;
+    float bound_r2;      // squared radius of a padded world-space bounding sphere about (cx,cy,cz) (culling only)
 };
 static_assert(sizeof(Prim) == 128, "Prim must be 128 B");
 

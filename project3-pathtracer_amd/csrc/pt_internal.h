@@ -53,6 +53,7 @@ struct KParams {
     const ptd::Prim *prims;
     const float *mats;     // M_PLANES planes of nM floats
     float *image;          // tile framebuffer, fp32 RGB packed (12 B/pixel)
+    int cull;              // 1 = skip primitives whose bounding sphere no lane of the wave can hit (large scenes)
     int nslot;             // iterations in flight in this launch sequence (1..PT_MAX_BATCH)
     float *lbuf;           // nslot planes of npix fp32 RGB radiance samples, folded into `image` by k_accumulate
     int nshard;            // pool segments in use: NSHARD (compaction 1), 1 otherwise

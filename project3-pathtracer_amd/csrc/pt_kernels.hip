@@ -24,6 +24,7 @@ namespace pt {
 using namespace ptd;
 
 static constexpr uint32_t DEAD = 0xFFFFFFFFu;
+static constexpr bool DEBUG_CULL = false;
 static constexpr int MAXSLOT = 4;                 // iterations in flight per launch sequence (pt_internal.h PT_MAX_BATCH)
 static constexpr uint32_t SLOT_SHIFT = 28;        // pixel word = tile-local pixel | slot << 28
 static constexpr uint32_t PIX_MASK = (1u << SLOT_SHIFT) - 1u;
@@ -58,6 +59,22 @@ struct Hit {
 //                      a 64-bit LDS atomic min on (distance bits, primitive index).
 enum { GEOM_SCALAR = 0, GEOM_LDS = 1, GEOM_QUEUE = 2 };
 
+// Conservative cull for large primitive lists: true when NO lane of the wave can hit the primitive, judged by a
+// padded world-space bounding sphere (centre = transform*(0,0,0,1), radius^2 in the record).  It only ever skips
+// primitives whose exact test would miss for every lane, so results are unchanged; the wave-uniform ballot makes
+// the skip a scalar branch.
+__device__ __forceinline__ bool waveMissesBound(const Prim &P, f3 o, f3 d)
+{
+    const f3 oc = o - mk(P.cx, P.cy, P.cz);
+    const float b = dot(oc, d);
+    const float oc2 = dot(oc, oc);
+    const float perp2 = oc2 - b * b;                       // squared distance of the centre from the ray's line
+    // origin outside and leaving, or the line passes outside the sphere; oc2*1e-5 covers the fp32 cancellation in
+    // perp2 and |d| = 1 +- 1e-6 (the radius itself is already padded by 2 % + 1e-3 on the host)
+    const bool reject = (oc2 > P.bound_r2 && b > 0.0f) || (perp2 > P.bound_r2 + oc2 * 1e-5f);
+    return __ballot(!reject) == 0ull;
+}
+
 template <int GEOM>
 __device__ __forceinline__ Hit nearestHitDirect(const KParams &p, const Prim *s_prims, f3 o, f3 d)
 {
@@ -73,10 +90,16 @@ __device__ __forceinline__ Hit nearestHitDirect(const KParams &p, const Prim *s_
         uint32_t mat;
         if (GEOM == GEOM_LDS) {
             const Prim &P = s_prims[g];
+            if (p.cull && waveMissesBound(P, o, d)) continue;
             t = intersectPrim(P, o, d, ip, in);
             mat = P.material;
         } else {
             const Prim P = load_prim_scalar(p.prims, g);
+            if (p.cull) {
+                const bool skip = waveMissesBound(P, o, d);
+                if (DEBUG_CULL && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicAdd(&p.st->clk[skip ? 3 : 2], 1ull);
+                if (skip) continue;
+            }
             t = intersectPrim(P, o, d, ip, in);
             mat = P.material;
         }

@@ -111,6 +111,16 @@ def test_cloud_256_primitives(pkg):
     check(g, c, lg, lc, "256-primitive cloud")
 
 
+@pytest.mark.parametrize("rotat", [0, 1])
+def test_cloud_cull_is_conservative(pkg, rotat):
+    """Large primitive lists are culled per wave with padded bounding spheres; the cull may only skip primitives no
+    lane can hit, so a bigger sample of the 256-primitive scene must still match the oracle bit for bit
+    (a wrongly culled hit shows up as an O(1) pixel error)."""
+    g, lg, _ = gpu_render(pkg, "cloud256.txt", 384, 216, 8, iters=2, rotat=rotat)
+    c, lc = cpu_render("cloud256.txt", 384, 216, 8, iters=2, rotat=rotat)
+    check(g, c, lg, lc, f"cloud256 cull rotat={rotat}")
+
+
 def test_seed_changes_image(pkg):
     a, _, _ = gpu_render(pkg, "sampleScene.txt", 128, 128, 4, seed=0)
     b, lb, _ = gpu_render(pkg, "sampleScene.txt", 128, 128, 4, seed=7)
