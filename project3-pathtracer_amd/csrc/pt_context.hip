@@ -66,6 +66,7 @@ struct pt_ctx {
     pt::LaunchCfg cfg;
     ptd::Prim *d_prims = nullptr;
     float *d_mats = nullptr;
+    float *d_ro_eye = nullptr;
     float *d_image_own = nullptr;
     float *d_image_bound = nullptr;
     size_t image_bytes = 0, image_cap = 0;
@@ -202,6 +203,20 @@ int configure(pt_ctx *c)
         HIP_TRY(hipMalloc((void **)&c->d_prims, prims.size() * sizeof(ptd::Prim)));
         HIP_TRY(hipMemcpy(c->d_prims, prims.data(), prims.size() * sizeof(ptd::Prim), hipMemcpyHostToDevice));
 
+        // camera rays all start at the eye: multiplyMV(inverseTransform, (eye,1)) once per primitive, with the
+        // reference's operation order (ref: src/intersections.h:53-59,85)
+        std::vector<float> ro(prims.size() * 4, 0.0f);
+        for (size_t i = 0; i < c->geoms.size(); ++i) {
+            const pt_mat4 &m = c->geoms[i].inverseTransform;
+            const float ex = c->cam.position.x, ey = c->cam.position.y, ez = c->cam.position.z;
+            ro[4 * i + 0] = (m.x.x * ex) + (m.x.y * ey) + (m.x.z * ez) + (m.x.w * 1.0f);
+            ro[4 * i + 1] = (m.y.x * ex) + (m.y.y * ey) + (m.y.z * ez) + (m.y.w * 1.0f);
+            ro[4 * i + 2] = (m.z.x * ex) + (m.z.y * ey) + (m.z.z * ez) + (m.z.w * 1.0f);
+        }
+        if (c->d_ro_eye) { (void)hipFree(c->d_ro_eye); c->d_ro_eye = nullptr; }
+        HIP_TRY(hipMalloc((void **)&c->d_ro_eye, ro.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(c->d_ro_eye, ro.data(), ro.size() * sizeof(float), hipMemcpyHostToDevice));
+
         const size_t nM = c->mats.size();
         std::vector<float> planes((nM ? nM : 1) * ptd::M_PLANES, 0.0f);
         for (size_t i = 0; i < nM; ++i) {
@@ -217,6 +232,7 @@ int configure(pt_ctx *c)
         HIP_TRY(hipMemcpy(c->d_mats, planes.data(), planes.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     k.prims = c->d_prims;
+    k.ro_eye = c->d_ro_eye;
     k.mats = c->d_mats;
 
     // framebuffer
@@ -391,6 +407,7 @@ void pt_destroy(pt_ctx *c)
     for (auto &t : c->timers) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }
     if (c->d_prims) (void)hipFree(c->d_prims);
     if (c->d_mats) (void)hipFree(c->d_mats);
+    if (c->d_ro_eye) (void)hipFree(c->d_ro_eye);
     if (c->d_image_own) (void)hipFree(c->d_image_own);
     if (c->d_pool) (void)hipFree(c->d_pool);
     if (c->d_lbuf) (void)hipFree(c->d_lbuf);

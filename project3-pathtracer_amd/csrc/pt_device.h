@@ -180,13 +180,16 @@ __device__ __forceinline__ f3 pointOnRay(f3 o, f3 d, float t) { return o + (t - 
 //         (DESIGN.md "Canonical semantics", box).
 // Box face code: bits 1..0 = axis, bit 2 = 1 when the object-space normal points along -axis.
 // ---------------------------------------------------------------------------------------------
+// RO_GIVEN: `ro` already holds inverseTransform*(origin,1) -- for camera rays it is the same for every lane and
+// is evaluated once per primitive on the host with the same operation order.
+template <bool RO_GIVEN = false>
 __device__ __forceinline__ bool candidateT(uint32_t type, const float *inv, f3 o, f3 d, f3 &ro, f3 &rd, float &t,
                                            uint32_t &face)
 {
     face = 0u;
     t = 0.0f;
     if (type > 1u) return false;                         // MESH: parsed by the loader, never has geometry
-    ro = mulMV(inv, o, 1.0f);
+    if (!RO_GIVEN) ro = mulMV(inv, o, 1.0f);
     rd = normalize(mulMV(inv, d, 0.0f));
     if (type == 0u) {
         float vDot = dot(ro, rd);
@@ -240,12 +243,13 @@ __device__ __forceinline__ f3 boxNormal(const float *fwd, uint32_t face)
 }
 
 // the three stages back to back (direct path: hit work is done inside the wave-uniform primitive loop)
-__device__ __forceinline__ float intersectPrim(const Prim &g, f3 o, f3 d, f3 &point, f3 &normal)
+template <bool RO_GIVEN = false>
+__device__ __forceinline__ float intersectPrim(const Prim &g, f3 o, f3 d, f3 ro_given, f3 &point, f3 &normal)
 {
-    f3 ro, rd;
+    f3 ro = ro_given, rd;
     float t;
     uint32_t face;
-    if (!candidateT(g.type, g.inv, o, d, ro, rd, t, face)) return -1.0f;
+    if (!candidateT<RO_GIVEN>(g.type, g.inv, o, d, ro, rd, t, face)) return -1.0f;
     f3 real;
     const float dist = hitPoint(g.fwd, o, ro, rd, t, real);
     point = real;

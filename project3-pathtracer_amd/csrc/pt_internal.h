@@ -51,6 +51,7 @@ struct KParams {
     int rr_start;
     uint32_t seed;
     const ptd::Prim *prims;
+    const float *ro_eye;   // per primitive: inverseTransform*(eye,1) as float4 (camera rays share their origin)
     const float *mats;     // M_PLANES planes of nM floats
     float *image;          // tile framebuffer, fp32 RGB packed (12 B/pixel)
     int cull;              // 1 = skip primitives whose bounding sphere no lane of the wave can hit (large scenes)

@@ -75,7 +75,14 @@ __device__ __forceinline__ bool waveMissesBound(const Prim &P, f3 o, f3 d)
     return __ballot(!reject) == 0ull;
 }
 
-template <int GEOM>
+// wave-uniform fetch of inverseTransform*(eye,1) of primitive g (camera rays only)
+__device__ __forceinline__ f3 load_ro_eye(const float *ro_eye, int g)
+{
+    const_u32_ptr q = (const_u32_ptr)(uintptr_t)(ro_eye + 4 * g);
+    return mk(__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]));
+}
+
+template <int GEOM, bool FIRST>
 __device__ __forceinline__ Hit nearestHitDirect(const KParams &p, const Prim *s_prims, f3 o, f3 d)
 {
     Hit h;
@@ -91,7 +98,7 @@ __device__ __forceinline__ Hit nearestHitDirect(const KParams &p, const Prim *s_
         if (GEOM == GEOM_LDS) {
             const Prim &P = s_prims[g];
             if (p.cull && waveMissesBound(P, o, d)) continue;
-            t = intersectPrim(P, o, d, ip, in);
+            t = intersectPrim<FIRST>(P, o, d, FIRST ? load_ro_eye(p.ro_eye, g) : o, ip, in);
             mat = P.material;
         } else {
             const Prim P = load_prim_scalar(p.prims, g);
@@ -100,7 +107,7 @@ __device__ __forceinline__ Hit nearestHitDirect(const KParams &p, const Prim *s_
                 if (DEBUG_CULL && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicAdd(&p.st->clk[skip ? 3 : 2], 1ull);
                 if (skip) continue;
             }
-            t = intersectPrim(P, o, d, ip, in);
+            t = intersectPrim<FIRST>(P, o, d, FIRST ? load_ro_eye(p.ro_eye, g) : o, ip, in);
             mat = P.material;
         }
         if (t > 0 && (!h.any || t < best_t)) {      // smallest t > 0, ties keep the lowest index
@@ -129,6 +136,7 @@ __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOM
 
 // Must be entered by all 64 lanes of the wave (lanes without a ray pass valid = false): lanes are consumers
 // of queued candidates independently of their own ray.
+template <bool FIRST>
 __device__ __forceinline__ Hit nearestHitQueued(const KParams &p, const Prim *s_prims, const WaveQueue q, f3 o, f3 d,
                                                 bool valid, uint32_t lane)
 {
@@ -144,10 +152,10 @@ __device__ __forceinline__ Hit nearestHitQueued(const KParams &p, const Prim *s_
             float inv[12];
 #pragma unroll
             for (int k = 0; k < 12; ++k) inv[k] = __uint_as_float(hp[4 + k]);
-            f3 ro = mk(0, 0, 0), rd = mk(0, 0, 0);
+            f3 ro = FIRST ? load_ro_eye(p.ro_eye, g) : mk(0, 0, 0), rd = mk(0, 0, 0);
             float t = 0.0f;
             uint32_t face = 0u;
-            const bool cand = valid && candidateT(type, inv, o, d, ro, rd, t, face);
+            const bool cand = valid && candidateT<FIRST>(type, inv, o, d, ro, rd, t, face);
             const uint64_t mask = __ballot(cand);
             if (mask != 0ull) {
                 if (cand) {
@@ -352,10 +360,10 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
         bool alive = false;
         Hit h;
         if (GEOM == GEOM_QUEUE) {
-            h = nearestHitQueued(p, s_prims, wq, o, d, valid, (uint32_t)lane);   // whole wave, see above
+            h = nearestHitQueued<FIRST>(p, s_prims, wq, o, d, valid, (uint32_t)lane);   // whole wave, see above
         } else {
             h.any = false;
-            if (valid) h = nearestHitDirect<GEOM>(p, s_prims, o, d);
+            if (valid) h = nearestHitDirect<GEOM, FIRST>(p, s_prims, o, d);
         }
         if (valid) {
             f3 L = mk(0, 0, 0);
