@@ -13,6 +13,8 @@
 //   PT_RR_START (-1)      first bounce with Russian roulette, -1 = off
 //   PT_SEED (0)           RNG stream selector
 //   PT_DEVICE (0)         HIP device
+//   PT_SHIM_BATCH (4)     iterations that may be pending inside the shim before they are rendered together
+//                         (only while nobody can observe them: no PBO, no read-back due); 1 = render every call
 //   PT_READBACK_EVERY (0) also copy the image back every N iterations (0 = only on the last one,
 //                         iterations == renderCam->iterations, which is when src/main.cpp:114-125 reads it);
 //                         1 reproduces the reference's copy on every call
@@ -34,7 +36,9 @@ struct ShimState {
     pt_camera_data cam;
     bool have_cam = false;
     int readback_every = 0;
-    int last_iteration = 0;     // the iteration the device framebuffer currently holds the mean of
+    int last_iteration = 0;     // the last iteration handed to this shim (rendered or pending)
+    int pend_first = 0, pend_count = 0;   // iterations accepted but not enqueued yet (rendered in batches)
+    int defer = 4;              // PT_SHIM_BATCH: how many iterations may be pending; 1 = render on every call
 };
 ShimState g;
 
@@ -52,6 +56,14 @@ void check(int rc, const char *msg)
     exit(EXIT_FAILURE);
 }
 
+// Iterations whose outputs nobody can observe yet (no PBO, no image read-back) are collected and rendered as one
+// pt_render call, so that the renderer can keep several of them in flight (pt_options.batch).
+void flush_pending()
+{
+    if (g.pend_count > 0) check(pt_render(g.ctx, g.pend_first, g.pend_count), "pt_render");
+    g.pend_count = 0;
+}
+
 }  // namespace
 
 void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iterations, material *materials,
@@ -66,6 +78,8 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
         o.seed = (unsigned)env_int("PT_SEED", 0);
         check(pt_set_options(g.ctx, &o), "pt_set_options");
         g.readback_every = env_int("PT_READBACK_EVERY", 0);
+        g.defer = env_int("PT_SHIM_BATCH", 4);
+        if (g.defer < 1) g.defer = 1;
     }
 
     // package geometry (ref: src/raytraceKernel.cu:123-134).  geom::frames is never initialised by the
@@ -91,6 +105,7 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
         (!list.empty() && memcmp(list.data(), g.geoms.data(), list.size() * sizeof(pt_static_geom)) != 0) ||
         (!mats.empty() && memcmp(mats.data(), g.mats.data(), mats.size() * sizeof(pt_material)) != 0);
     if (scene_changed) {
+        flush_pending();                       // pending iterations belong to the previous scene
         check(pt_set_scene(g.ctx, list.data(), numberOfGeoms, mats.data(), numberOfMaterials), "pt_set_scene");
         g.geoms = list;
         g.mats = mats;
@@ -105,6 +120,7 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
     memcpy(&cam.up, &renderCam->ups[frame], sizeof cam.up);
     cam.fov = {renderCam->fov.x, renderCam->fov.y};
     if (!g.have_cam || memcmp(&cam, &g.cam, sizeof cam) != 0) {
+        flush_pending();
         check(pt_set_camera(g.ctx, &cam), "pt_set_camera");
         g.cam = cam;
         g.have_cam = true;
@@ -115,12 +131,18 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
     float *host_image = reinterpret_cast<float *>(renderCam->image);
     const bool last = (unsigned)iterations >= renderCam->iterations;
     const bool readback = host_image && (last || (g.readback_every > 0 && iterations % g.readback_every == 0));
-    if (iterations > 1 && iterations != g.last_iteration + 1 && host_image)
-        check(pt_upload_image(g.ctx, host_image), "pt_upload_image");
-    check(pt_render(g.ctx, iterations, 1), "pt_render");
-    if (PBOpos) check(pt_send_image_to_pbo(g.ctx, reinterpret_cast<pt_uchar4 *>(PBOpos)), "pt_send_image_to_pbo");
-    if (readback) check(pt_download_image(g.ctx, host_image), "pt_download_image");
-    // make certain the kernels have completed (ref: src/raytraceKernel.cu:162-164)
-    check(pt_synchronize(g.ctx), "Kernel failed!");
+    if (iterations != g.last_iteration + 1) {
+        flush_pending();                       // not the continuation of what is pending
+        if (iterations > 1 && host_image) check(pt_upload_image(g.ctx, host_image), "pt_upload_image");
+    }
+    if (g.pend_count == 0) g.pend_first = iterations;
+    g.pend_count++;
     g.last_iteration = iterations;
+    if (PBOpos || readback || g.pend_count >= g.defer) {
+        flush_pending();
+        if (PBOpos) check(pt_send_image_to_pbo(g.ctx, reinterpret_cast<pt_uchar4 *>(PBOpos)), "pt_send_image_to_pbo");
+        if (readback) check(pt_download_image(g.ctx, host_image), "pt_download_image");
+        // make certain the kernels have completed (ref: src/raytraceKernel.cu:162-164)
+        check(pt_synchronize(g.ctx), "Kernel failed!");
+    }
 }

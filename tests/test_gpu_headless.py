@@ -1,0 +1,59 @@
+"""End-to-end drop-in test on the GPU: the headless driver (reference main.cpp protocol) -> cudaRaytraceCore shim
+-> C-ABI -> HIP kernels -> BMP, compared with the oracle's image pushed through the reference's write-out rules
+(x flip, clamp(v*255, 0, 255) truncation; ref src/main.cpp:116-141, src/image.cpp:41-88)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def read_bmp(path):
+    raw = open(path, "rb").read()
+    assert raw[:2] == b"BM"
+    w, h = struct.unpack("<ii", raw[18:26])
+    stride = (w * 3 + 3) // 4 * 4
+    img = np.zeros((h, w, 3), np.uint8)
+    for y in range(h):
+        row = np.frombuffer(raw[54 + (h - 1 - y) * stride: 54 + (h - 1 - y) * stride + w * 3], np.uint8).reshape(w, 3)
+        img[y] = row[:, ::-1]
+    return img
+
+
+@pytest.mark.parametrize("shim_batch,iters", [(4, 7), (1, 3), (4, 4)])
+def test_headless_driver_matches_oracle(tmp_path, shim_batch, iters):
+    pkg = load_package()
+    assert os.path.exists(pkg.HEADLESS_PATH)
+    W, H, depth = 96, 64, 4
+    scene = os.path.join(ROOT, "scenes", "sampleScene_spec.txt")
+    env = dict(os.environ, PT_DEPTH=str(depth), PT_SHIM_BATCH=str(shim_batch))
+    res = subprocess.run([pkg.HEADLESS_PATH, f"scene={scene}", "frame=0", f"res={W}x{H}", f"iterations={iters}",
+                          f"out={tmp_path}"], env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "Saved frame 0" in res.stdout
+    got = read_bmp(os.path.join(tmp_path, "spec.0.bmp"))
+
+    sc = O.LoadedScene(scene)
+    sc.set_resolution(W, H)
+    ref, _ = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, depth, iters=iters)
+    q = np.clip(ref * np.float32(255.0), 0, 255).astype(np.uint8)[:, ::-1, :]      # buffer x -> picture W-1-x
+    assert got.shape == q.shape
+    assert np.array_equal(got, q)
+
+
+def test_headless_error_convention(tmp_path):
+    """The shim keeps checkCUDAError's print-and-exit convention (ref src/raytraceKernel.cu:19-25)."""
+    pkg = load_package()
+    scene = os.path.join(ROOT, "scenes", "sampleScene.txt")
+    env = dict(os.environ, PT_DEPTH="0")       # invalid depth -> pt_set_options fails inside the shim
+    res = subprocess.run([pkg.HEADLESS_PATH, f"scene={scene}", "res=16x16", "iterations=1", f"out={tmp_path}"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0
+    assert "Cuda error:" in res.stderr
