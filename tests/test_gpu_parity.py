@@ -373,3 +373,50 @@ def test_full_size_properties_1080p(pkg):
                     for u, v in zip(l1.tup(), l2.tup())]
             # running mean: it=1 -> (0*0 + L1)/1 = L1 ; it=2 -> (L1*1 + L2)/2
             assert np.allclose(a[y, x], want, atol=TOL, rtol=0), (x, y)
+
+
+# ---------------------------------------------------------------- randomized scenes
+def _random_scene(seed, n_prims):
+    rng = np.random.default_rng(seed)
+    mats = [O.make_material(color=rng.uniform(0.1, 1.0, 3)),
+            O.make_material(color=rng.uniform(0.1, 1.0, 3)),
+            O.make_material(color=(0.9, 0.9, 0.9), spec=rng.uniform(0.5, 1.0, 3), refl=1.0),
+            O.make_material(color=(0, 0, 0), spec=(1, 1, 1), refr=1.0, ior=float(rng.uniform(1.2, 2.4))),
+            O.make_material(color=(1, 1, 1), emittance=float(rng.uniform(2, 20)))]
+    geoms = []
+    # an enclosing room (one big cube seen from inside), a light, then random spheres / cubes, some overlapping
+    geoms.append(O.make_geom(O.CUBE, 0, (0, 0, 0), rng.uniform(-3, 3, 3), (14, 12, 16)))
+    geoms.append(O.make_geom(O.CUBE if rng.random() < 0.5 else O.SPHERE, 4, (0, 4.5, 0), rng.uniform(-3, 3, 3), (4, 0.6, 4)))
+    for _ in range(n_prims - 2):
+        kind = O.SPHERE if rng.random() < 0.5 else O.CUBE
+        s = rng.uniform(0.3, 3.0, 3) if rng.random() < 0.5 else np.full(3, rng.uniform(0.3, 3.0))
+        geoms.append(O.make_geom(kind, int(rng.integers(0, 4)), rng.uniform(-5, 5, 3), rng.uniform(-3.2, 3.2, 3), s))
+    eye = rng.uniform(-2, 2, 3)
+    view = rng.normal(size=3)
+    view /= np.linalg.norm(view)
+    up = np.cross(view, rng.normal(size=3))
+    up /= np.linalg.norm(up)
+    return geoms, mats, eye, view, up, float(rng.uniform(15, 40))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_bit_exact(pkg, seed):
+    """Random TRS primitives (overlapping, camera possibly inside objects), all material lobes, random cameras:
+    every geometry path of the kernel must reproduce the oracle."""
+    n_prims = [3, 6, 9, 17, 40, 70][seed % 6]
+    geoms, mats, eye, view, up, fovy = _random_scene(1000 + seed, n_prims)
+    W, H, depth, iters = 73, 41, 7, 2
+    ga = (O.StaticGeom * len(geoms))(*geoms)
+    ma = (O.Material * len(mats))(*mats)
+    cam = O.make_camera(W, H, eye, view, up, fovy)
+    ref, live = O.render(ga, len(geoms), ma, len(mats), cam, depth, iters=iters, rr_start=3, seed=seed)
+    for geom_path in (1, 3) if n_prims <= 32 else (1, 2):
+        with pkg.Renderer(0) as r:
+            r.set_options(depth=depth, rr_start=3, seed=seed, geom_path=geom_path)
+            r.set_scene(C.cast(ga, C.POINTER(pkg.StaticGeom)), len(geoms), C.cast(ma, C.POINTER(pkg.Material)), len(mats))
+            r.set_camera(pkg.CameraData.from_buffer_copy(cam))
+            r.clear_image()
+            r.render(1, iters)
+            img = r.download_image()
+            st = r.stats()
+        check(img, ref, [int(x) for x in st.live_in[:depth]], [int(x) for x in live], f"random scene {seed} geom_path={geom_path}")
