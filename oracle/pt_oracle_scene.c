@@ -187,6 +187,8 @@ static int safe_getline(FILE *f, char *buf, size_t cap, int *eof)
     return (int)n;
 }
 
+static int g_frame = 0;      /* which animation frame o_scene_load_frame keeps (ref: src/sceneStructs.h:21-30) */
+
 #define MAXTOK 8
 static int tokenize(char *line, char *tok[MAXTOK])
 {
@@ -264,7 +266,7 @@ static int load_camera(FILE *f, o_scene *s, int *eof)
             n = tokenize(line, t);
             if (n == 0) continue;
             o_vec3 v = { tokf(t, n, 1), tokf(t, n, 2), tokf(t, n, 3) };
-            if (frames == 0) {                             /* the oracle keeps frame 0 only */
+            if (frames == g_frame) {                       /* the oracle keeps one frame */
                 if (!strcmp(t[0], "EYE")) s->camera.position = v;
                 else if (!strcmp(t[0], "VIEW")) s->camera.view = v;
                 else if (!strcmp(t[0], "UP")) s->camera.up = v;
@@ -306,7 +308,7 @@ static int load_object(FILE *f, const char *idtok, geom_vec *gv, int rotat_units
             n = tokenize(line, t);
             if (n == 0) continue;
             o_vec3 v = { tokf(t, n, 1), tokf(t, n, 2), tokf(t, n, 3) };
-            if (frames == 0) {
+            if (frames == g_frame) {
                 if (!strcmp(t[0], "TRANS")) g.translation = v;
                 else if (!strcmp(t[0], "ROTAT")) g.rotation = v;
                 else if (!strcmp(t[0], "SCALE")) g.scale = v;
@@ -319,6 +321,14 @@ static int load_object(FILE *f, const char *idtok, geom_vec *gv, int rotat_units
     if (gv->n == gv->cap) { gv->cap = gv->cap ? 2 * gv->cap : 16; gv->v = (o_staticGeom *)realloc(gv->v, (size_t)gv->cap * sizeof g); }
     gv->v[gv->n++] = g;
     return 1;
+}
+
+int o_scene_load_frame(const char *path, int rotat_units, int frame, o_scene *out)
+{
+    g_frame = frame;
+    int rc = o_scene_load(path, rotat_units, out);
+    g_frame = 0;
+    return rc;
 }
 
 int o_scene_load(const char *path, int rotat_units, o_scene *out)

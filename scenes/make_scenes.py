@@ -33,6 +33,29 @@ def fmt(v):
     return str(v)
 
 
+def emit_animated(path, materials, camera_frames, camera, objects_frames):
+    """objects_frames: list of (kind, material, [(t, r, s) per frame]); camera_frames: [(eye, view, up) per frame]."""
+    out = []
+    for i, m in enumerate(materials):
+        out.append(f"MATERIAL {i}")
+        for k in MAT_KEYS:
+            out.append(f"{k} {fmt(m[k])}")
+        out.append("")
+    out += ["CAMERA", f"RES {camera['res'][0]} {camera['res'][1]}", f"FOVY {fmt(camera['fovy'])}",
+            f"ITERATIONS {camera['iterations']}", f"FILE {camera['file']}"]
+    for f, (eye, view, up) in enumerate(camera_frames):
+        out += [f"frame {f}", f"EYE {fmt(eye)}", f"VIEW {fmt(view)}", f"UP {fmt(up)}"]
+    out.append("")
+    for i, (kind, material, frames) in enumerate(objects_frames):
+        out += [f"OBJECT {i}", kind, f"material {material}"]
+        for f, (t, r, sc) in enumerate(frames):
+            out += [f"frame {f}", f"TRANS {fmt(t)}", f"ROTAT {fmt(r)}", f"SCALE {fmt(sc)}"]
+        out.append("")
+    with open(os.path.join(HERE, path), "w") as fh:
+        fh.write("\n".join(out))
+    print("wrote", path, len(objects_frames), "objects,", len(camera_frames), "frames")
+
+
 def emit(path, materials, camera, objects):
     out = []
     for i, m in enumerate(materials):
@@ -158,6 +181,18 @@ if __name__ == "__main__":
     ]
     emit("cornell_glass.txt", SAMPLE_MATERIALS, dict(SAMPLE_CAMERA, res=(1920, 1080), iterations=1024, file="glass.bmp"),
          glass_objects)
+
+    # three animation frames: the spheres move, the camera dollies (ref: src/sceneStructs.h:21-30,50-61)
+    anim_objects = []
+    for (kind, material, t, r, sc) in SAMPLE_OBJECTS:
+        frames = []
+        for f in range(3):
+            tt = (t[0] + 0.6 * f, t[1] + 0.3 * f, t[2] - 0.4 * f) if kind == "sphere" else t
+            frames.append((tt, (r[0], r[1] + (25 * f if kind == "sphere" else 0), r[2]), sc))
+        anim_objects.append((kind, material, frames))
+    anim_cam = [((0, 4.5, 12 - 1.5 * f), (0.05 * f, 0, -1), (0, 1, 0)) for f in range(3)]
+    emit_animated("sampleScene_anim.txt", spec, anim_cam, dict(SAMPLE_CAMERA, res=(320, 240), iterations=8, file="anim.bmp"),
+                  anim_objects)
 
     cm, co = cloud()
     emit("cloud256.txt", cm, dict(SAMPLE_CAMERA, res=(1920, 1080), iterations=4096, file="cloud.bmp"), co)

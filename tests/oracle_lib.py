@@ -123,6 +123,7 @@ def lib():
         "o_buildTransformationMatrix": (Mat4, [Vec3, Vec3, Vec3, i, P(Mat4)]),
         "o_camera_fov": (Vec2, [f, Vec2]),
         "o_scene_load": (i, [C.c_char_p, i, P(Scene)]),
+        "o_scene_load_frame": (i, [C.c_char_p, i, i, P(Scene)]),
         "o_scene_free": (None, [P(Scene)]),
     }
     for name, (res, args) in sig.items():
@@ -181,9 +182,9 @@ def make_camera(w, h, eye, view, up, fovy):
 class LoadedScene:
     """Scene loaded by the oracle's loader, as ctypes arrays."""
 
-    def __init__(self, path, rotat_units=ROTAT_RADIANS):
+    def __init__(self, path, rotat_units=ROTAT_RADIANS, frame=0):
         s = Scene()
-        rc = lib().o_scene_load(path.encode(), rotat_units, C.byref(s))
+        rc = lib().o_scene_load_frame(path.encode(), rotat_units, frame, C.byref(s))
         if rc != 0:
             raise IOError(f"oracle loader failed on {path}: {rc}")
         self.n_objects, self.n_materials = s.n_objects, s.n_materials

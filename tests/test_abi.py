@@ -169,3 +169,22 @@ def test_image_write_out_flip_and_quantisation(pkg, tmp_path):
     stride = (W * 3 + 3) // 4 * 4
     row0 = raw[54 + (H - 1) * stride: 54 + (H - 1) * stride + W * 3]
     assert tuple(row0[-3:]) == (63, 127, 255)
+
+
+# ---------------------------------------------------------------- animation frames (ref src/sceneStructs.h:21-30,50-61)
+@pytest.mark.parametrize("frame", [0, 1, 2])
+def test_animation_frames_product_loader_equals_oracle(pkg, frame):
+    path = os.path.join(SCENES, "sampleScene_anim.txt")
+    a = pkg.SceneFile(path, 1, frame=frame)
+    b = O.LoadedScene(path, 1, frame=frame)
+    assert a.n_camera_frames == 3 and b.n_frames_camera == 3
+    assert bytes(a.geoms)[: a.n_objects * 172] == bytes(b.geoms)[: b.n_objects * 172]
+    assert bytes(a.camera) == bytes(b.camera)
+    if frame:
+        f0 = pkg.SceneFile(path, 1, frame=0)
+        assert bytes(a.geoms) != bytes(f0.geoms) and bytes(a.camera) != bytes(f0.camera)
+
+
+def test_animation_frame_out_of_range(pkg):
+    with pytest.raises(pkg.PtError):
+        pkg.SceneFile(os.path.join(SCENES, "sampleScene_anim.txt"), 0, frame=3)

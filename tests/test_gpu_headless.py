@@ -57,3 +57,24 @@ def test_headless_error_convention(tmp_path):
                          env=env, capture_output=True, text=True, timeout=120)
     assert res.returncode != 0
     assert "Cuda error:" in res.stderr
+
+
+def test_headless_renders_every_animation_frame(tmp_path):
+    """No `frame=` argument: the driver walks all frames like the reference's runCuda (ref src/main.cpp:142-157),
+    one image file per frame, each equal to the oracle's render of that frame."""
+    pkg = load_package()
+    W, H, depth, iters = 80, 60, 4, 3
+    scene = os.path.join(ROOT, "scenes", "sampleScene_anim.txt")
+    env = dict(os.environ, PT_DEPTH=str(depth))
+    res = subprocess.run([pkg.HEADLESS_PATH, f"scene={scene}", f"res={W}x{H}", f"iterations={iters}", "rotat=degrees",
+                          f"out={tmp_path}"], env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    for frame in range(3):
+        got = read_bmp(os.path.join(tmp_path, f"anim.{frame}.bmp"))
+        sc = O.LoadedScene(scene, O.ROTAT_DEGREES, frame=frame)
+        sc.set_resolution(W, H)
+        ref, _ = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, depth, iters=iters)
+        q = np.clip(ref * np.float32(255.0), 0, 255).astype(np.uint8)[:, ::-1, :]
+        assert np.array_equal(got, q), f"frame {frame}"
+    frames = [read_bmp(os.path.join(tmp_path, f"anim.{f}.bmp")) for f in range(3)]
+    assert not np.array_equal(frames[0], frames[1]) and not np.array_equal(frames[1], frames[2])
