@@ -156,6 +156,27 @@ int  pt_render_profiled(pt_ctx *ctx, int iter_first, int iter_count, double *bou
  * the compiler's general ones for ALL 2^32 fp32 inputs.  mismatches_out[0..2] must come back 0. */
 int  pt_selftest_math(pt_ctx *ctx, unsigned long long mismatches_out[3]);
 
+/* Known-answer tests of single DEVICE functions (one GPU thread evaluates the kernels' own implementation of
+ * a reference function), so that GPU results can be pinned directly to the reference's golden vectors.
+ * `in` / `out` are host arrays of fp32; integers travel as bit patterns.  Transforms are 16 floats, row-major
+ * rows x,y,z,w (cudaMat4).  Synchronous. */
+enum {
+    PT_KAT_HASH = 1,            /* in: a (bits)                                  out: hash(a) (bits)      ref src/intersections.h:26-34 */
+    PT_KAT_U01_SEQUENCE = 2,    /* in: engine seed (bits)                        out: n_out u01 draws      thrust minstd_rand + uniform_real */
+    PT_KAT_NOISE = 3,           /* in: resx, resy, time, x, y                    out: rgb                  ref src/raytraceKernel.cu:29-36 */
+    PT_KAT_INTERSECT = 4,       /* in: type (bits), transform[16], inverse[16], o[3], d[3]   out: t, p[3], n[3]   ref src/intersections.h:72-117 */
+    PT_KAT_HEMISPHERE = 5,      /* in: n[3], xi1, xi2                            out: dir[3]               ref src/interactions.h:62-87 */
+    PT_KAT_RADIUSES = 6,        /* in: transform[16]                             out: radii[3]             ref src/intersections.h:120-129 */
+    PT_KAT_POINT_ON_CUBE = 7,   /* in: transform[16], seed                       out: p[3]                 ref src/intersections.h:133-175 */
+    PT_KAT_POINT_ON_SPHERE = 8, /* in: transform[16], seed                       out: p[3]                 ref src/intersections.h:177-182 */
+    PT_KAT_MULTIPLY_MV = 9,     /* in: m[16], v[4]                               out: r[3]                 ref src/intersections.h:53-59 */
+    PT_KAT_POINT_ON_RAY = 10,   /* in: o[3], d[3], t                             out: p[3]                 ref src/intersections.h:46-48 */
+    PT_KAT_REFLECT = 11,        /* in: normal[3], incident[3]                    out: dir[3]               ref src/interactions.h:47-50 */
+    PT_KAT_REFRACT = 12,        /* in: normal[3], incident[3], n1, n2            out: dir[3] (0 on TIR)    ref src/interactions.h:42-44 */
+    PT_KAT_FRESNEL = 13         /* in: normal[3], incident[3], n1, n2, trans[3]  out: reflectance          ref src/interactions.h:53-59 */
+};
+int  pt_device_kat(pt_ctx *ctx, int op, const float *in, int n_in, float *out, int n_out);
+
 /* ---- scene files (ref: src/scene.cpp, src/utilities.cpp:74-90; format README.md:160-217) ---- */
 enum { PT_ROTAT_RADIANS = 0,   /* what the reference binary does (GLM_FORCE_RADIANS, ref: src/utilities.cpp:7) */
        PT_ROTAT_DEGREES = 1 }; /* what the scene author evidently meant */

@@ -130,6 +130,7 @@ def lib():
         "pt_reset_stats": (i, [vp]),
         "pt_render_profiled": (i, [vp, i, i, P(C.c_double)]),
         "pt_selftest_math": (i, [vp, P(C.c_ulonglong)]),
+        "pt_device_kat": (i, [vp, i, vp, i, vp, i]),
         "pt_scene_load": (i, [cp, i, P(vp)]),
         "pt_scene_free": (None, [vp]),
         "pt_scene_counts": (i, [vp, P(i), P(i), P(i)]),
@@ -267,6 +268,13 @@ class Renderer:
         ms = (C.c_double * PT_MAX_DEPTH)()
         _check(self.L.pt_render_profiled(self.h, iter_first, iter_count, ms), "pt_render_profiled")
         return [float(ms[b]) for b in range(self.opt.depth)]
+
+    def device_kat(self, op, inputs, n_out):
+        """Evaluate one device function on the GPU (include/pt_abi.h PT_KAT_*); inputs/outputs are float32 arrays."""
+        a = np.ascontiguousarray(inputs, dtype=np.float32)
+        out = np.zeros(n_out, dtype=np.float32)
+        _check(self.L.pt_device_kat(self.h, op, a.ctypes.data, a.size, out.ctypes.data, n_out), "pt_device_kat")
+        return out
 
     def selftest_math(self):
         """Mismatch counts of the kernels' exact sqrt / rcp / rsqrt sequences over all 2^32 inputs (must be 0)."""

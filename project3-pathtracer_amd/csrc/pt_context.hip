@@ -619,6 +619,25 @@ int pt_selftest_math(pt_ctx *c, unsigned long long mismatches_out[3])
     return PT_OK;
 }
 
+int pt_device_kat(pt_ctx *c, int op, const float *in, int n_in, float *out, int n_out)
+{
+    if (!c || !in || !out || n_in < 1 || n_out < 1 || n_in > 4096 || n_out > 4096)
+        return fail(PT_ERR_INVALID, "pt_device_kat: bad arguments");
+    static const int need_in[] = {0, 1, 1, 5, 39, 5, 16, 17, 17, 20, 7, 6, 8, 11};
+    if (op < 1 || op > 13 || n_in < need_in[op]) return fail(PT_ERR_INVALID, "pt_device_kat: op %d needs %d inputs", op, op >= 1 && op <= 13 ? need_in[op] : 0);
+    HIP_TRY(hipSetDevice(c->device));
+    float *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, (size_t)(n_in + n_out) * sizeof(float)));
+    hipError_t e = hipMemcpy(d, in, (size_t)n_in * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d + n_in, 0, (size_t)n_out * sizeof(float));
+    if (e == hipSuccess) e = pt::launch_device_kat(c->stream, op, d, d + n_in, n_out);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d + n_in, (size_t)n_out * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(PT_ERR_HIP, "pt_device_kat: %s", hipGetErrorString(e));
+    return PT_OK;
+}
+
 int pt_send_image_to_pbo(pt_ctx *c, pt_uchar4 *device_pbo)
 {
     if (!c || !device_pbo) return fail(PT_ERR_INVALID, "pt_send_image_to_pbo: NULL argument");

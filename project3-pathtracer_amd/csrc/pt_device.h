@@ -306,4 +306,74 @@ __device__ __forceinline__ float fresnelReflectance(f3 normal, f3 incident, floa
     return 0.5f * (rs * rs + rp * rp);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sampling helpers of intersections.h / interactions.h / raytraceKernel.cu that are not on the pure
+// path-tracing path but belong to the reference's device interface; exercised on the
+// GPU by pt_device_kat() against the reference's golden vectors.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float uniform_real(uint32_t &state, float a, float b)    // thrust uniform_real_distribution<float>
+{
+    state = minstd_next(state);
+    float r = (float)(state - 1u);
+    r /= (1.0f + (float)(2147483646u - 1u));
+    return (r * (b - a)) + a;
+}
+
+// generateRandomNumberFromThread (ref: src/raytraceKernel.cu:29-36): index and the seed product are float arithmetic
+__device__ __forceinline__ f3 generateRandomNumberFromThread(float resx, float time, int x, int y)
+{
+    const int index = (int)((float)x + ((float)y * resx));
+    uint32_t s = minstd_seed(wang_hash((uint32_t)((float)index * time)));
+    const float a = uniform_real(s, 0, 1), b = uniform_real(s, 0, 1), c = uniform_real(s, 0, 1);
+    return mk(a, b, c);
+}
+
+// getRadiuses (ref: src/intersections.h:120-129); glm::distance(p0,p1) = length(p1 - p0)
+__device__ __forceinline__ f3 getRadiuses(const float *fwd)
+{
+    const f3 origin = mulMV(fwd, mk(0, 0, 0), 1.0f);
+    const f3 xmax = mulMV(fwd, mk(.5f, 0, 0), 1.0f), ymax = mulMV(fwd, mk(0, .5f, 0), 1.0f), zmax = mulMV(fwd, mk(0, 0, .5f), 1.0f);
+    return mk(length(xmax - origin), length(ymax - origin), length(zmax - origin));
+}
+
+// getRandomPointOnCube (ref: src/intersections.h:133-175): area-weighted face choice, then a point on the face
+__device__ __forceinline__ f3 getRandomPointOnCube(const float *fwd, float randomSeed)
+{
+    uint32_t rng = minstd_seed(wang_hash((uint32_t)randomSeed));
+    const f3 radii = getRadiuses(fwd);
+    const float side1 = radii.x * radii.y * 4.0f, side2 = radii.z * radii.y * 4.0f, side3 = radii.x * radii.z * 4.0f;
+    const float totalarea = 2.0f * (side1 + side2 + side3);
+    const float russianRoulette = uniform_real(rng, 0, 1);
+    const float a = uniform_real(rng, -0.5f, 0.5f), b = uniform_real(rng, -0.5f, 0.5f);
+    f3 point;
+    if (russianRoulette < (side1 / totalarea)) point = mk(a, b, .5f);
+    else if (russianRoulette < ((side1 * 2) / totalarea)) point = mk(a, b, -.5f);
+    else if (russianRoulette < (((side1 * 2) + (side2)) / totalarea)) point = mk(.5f, a, b);
+    else if (russianRoulette < (((side1 * 2) + (side2 * 2)) / totalarea)) point = mk(-.5f, a, b);
+    else if (russianRoulette < (((side1 * 2) + (side2 * 2) + (side3)) / totalarea)) point = mk(a, .5f, b);
+    else point = mk(a, -.5f, b);
+    return mulMV(fwd, point, 1.0f);
+}
+
+// getRandomDirectionInSphere (stub ref: src/interactions.h:89-95): uniform direction, deterministic trig
+__device__ __forceinline__ f3 getRandomDirectionInSphere(float xi1, float xi2)
+{
+    const float z = 1.0f - 2.0f * xi1;
+    const float rr = 1.0f - z * z;
+    const float rad = sqrt_rn(rr < 0.0f ? 0.0f : rr);
+    const float around = (float)((double)xi2 * 6.2831853071795864769252867665590057683943);
+    float sn, cs;
+    sincos_poly(around, sn, cs);
+    return mk(rad * cs, rad * sn, z);
+}
+
+// getRandomPointOnSphere (stub ref: src/intersections.h:177-182): uniform point on the object-space sphere r = .5
+__device__ __forceinline__ f3 getRandomPointOnSphere(const float *fwd, float randomSeed)
+{
+    uint32_t rng = minstd_seed(wang_hash((uint32_t)randomSeed));
+    const float xi1 = uniform_real(rng, 0, 1), xi2 = uniform_real(rng, 0, 1);
+    const f3 d = getRandomDirectionInSphere(xi1, xi2);
+    return mulMV(fwd, 0.5f * d, 1.0f);
+}
+
 }  // namespace ptd

@@ -78,6 +78,7 @@ hipError_t launch_iter_fold(hipStream_t s, IterState *st, int depth);
 hipError_t launch_bounce(hipStream_t s, const KParams &p, const LaunchCfg &cfg, int bounce);
 hipError_t launch_send_image_to_pbo(hipStream_t s, pt_uchar4 *pbo, const float *image, int npix);
 hipError_t launch_selftest_math(hipStream_t s, unsigned long long *out3);
+hipError_t launch_device_kat(hipStream_t s, int op, const float *in, float *out, int n_out);
 size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg);
 int bounce_max_blocks_per_cu(const KParams &p, const LaunchCfg &cfg);
 

@@ -515,6 +515,60 @@ __global__ __launch_bounds__(256) void k_selftest_math(unsigned long long *out)
     if (bad2) atomicAdd(&out[2], bad2);
 }
 
+// ---------------------------------------------------------------------------------------------
+// known-answer tests of the device functions (one thread): see pt_device_kat() in include/pt_abi.h
+// ---------------------------------------------------------------------------------------------
+__global__ void k_device_kat(int op, const float *in, float *out, int n_out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    auto u = [&](int k) { return __float_as_uint(in[k]); };
+    auto put3 = [&](int k, f3 v) { out[k] = v.x; out[k + 1] = v.y; out[k + 2] = v.z; };
+    switch (op) {
+    case PT_KAT_HASH: out[0] = __uint_as_float(wang_hash(u(0))); break;
+    case PT_KAT_U01_SEQUENCE: {
+        uint32_t s = minstd_seed(u(0));
+        for (int k = 0; k < n_out; ++k) { s = minstd_next(s); out[k] = u01_of(s); }
+        break;
+    }
+    case PT_KAT_NOISE: put3(0, generateRandomNumberFromThread(in[0], in[2], (int)in[3], (int)in[4])); break;
+    case PT_KAT_INTERSECT: {
+        Prim P;
+        P.type = u(0);
+        for (int k = 0; k < 12; ++k) { P.fwd[k] = in[1 + k]; P.inv[k] = in[17 + k]; }
+        const f3 c = mulMV(P.fwd, mk(0, 0, 0), 1.0f);
+        P.cx = c.x; P.cy = c.y; P.cz = c.z;
+        f3 p = mk(0, 0, 0), n = mk(0, 0, 0);
+        const f3 o = mk(in[33], in[34], in[35]), d = mk(in[36], in[37], in[38]);
+        out[0] = intersectPrim<false>(P, o, d, o, p, n);
+        put3(1, p);
+        put3(4, n);
+        break;
+    }
+    case PT_KAT_HEMISPHERE: put3(0, randomDirectionInHemisphere(mk(in[0], in[1], in[2]), in[3], in[4])); break;
+    case PT_KAT_RADIUSES: put3(0, getRadiuses(in)); break;
+    case PT_KAT_POINT_ON_CUBE: put3(0, getRandomPointOnCube(in, in[16])); break;
+    case PT_KAT_POINT_ON_SPHERE: put3(0, getRandomPointOnSphere(in, in[16])); break;
+    case PT_KAT_MULTIPLY_MV: put3(0, mulMV(in, mk(in[16], in[17], in[18]), in[19])); break;
+    case PT_KAT_POINT_ON_RAY: put3(0, pointOnRay(mk(in[0], in[1], in[2]), mk(in[3], in[4], in[5]), in[6])); break;
+    case PT_KAT_REFLECT: put3(0, reflectionDirection(mk(in[0], in[1], in[2]), mk(in[3], in[4], in[5]))); break;
+    case PT_KAT_REFRACT: {
+        bool tir;
+        put3(0, transmissionDirection(mk(in[0], in[1], in[2]), mk(in[3], in[4], in[5]), in[6], in[7], tir));
+        break;
+    }
+    case PT_KAT_FRESNEL:
+        out[0] = fresnelReflectance(mk(in[0], in[1], in[2]), mk(in[3], in[4], in[5]), in[6], in[7], mk(in[8], in[9], in[10]));
+        break;
+    default: break;
+    }
+}
+
+hipError_t launch_device_kat(hipStream_t s, int op, const float *in, float *out, int n_out)
+{
+    hipLaunchKernelGGL(k_device_kat, dim3(1), dim3(64), 0, s, op, in, out, n_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_selftest_math(hipStream_t s, unsigned long long *out)
 {
     hipLaunchKernelGGL(k_selftest_math, dim3(256 * 8), dim3(256), 0, s, out);
