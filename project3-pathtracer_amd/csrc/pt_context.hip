@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -67,6 +68,7 @@ struct pt_ctx {
     ptd::Prim *d_prims = nullptr;
     float *d_mats = nullptr;
     float *d_ro_eye = nullptr;
+    ptd::BvhNode *d_bvh = nullptr;
     float *d_image_own = nullptr;
     float *d_image_bound = nullptr;
     size_t image_bytes = 0, image_cap = 0;
@@ -109,6 +111,60 @@ int fold_timers(pt_ctx *c)
 }
 
 float *image_ptr(pt_ctx *c) { return c->d_image_bound ? c->d_image_bound : c->d_image_own; }
+
+// ---- culling hierarchy over the primitives (host build; the kernels only read it) -------------------------
+struct Aabb { float lo[3], hi[3]; };
+
+// Padded world-space box of one primitive: |x_a - c_a| <= 0.5 * sum_i |M[a][i]| for the unit cube and
+// <= 0.5 * sqrt(sum_i M[a][i]^2) for the r = .5 sphere (M = rows 0..2 of the transform); +1 % and +1e-3 absorb the
+// fp32 rounding of the traversal's slab test and the 1e-4 back-off of getPointOnRay.
+Aabb prim_bounds(const pt_static_geom &g)
+{
+    const float *rows[3] = {&g.transform.x.x, &g.transform.y.x, &g.transform.z.x};
+    Aabb b;
+    for (int a = 0; a < 3; ++a) {
+        const double m0 = rows[a][0], m1 = rows[a][1], m2 = rows[a][2], c = rows[a][3];
+        double h = (g.type == PT_SPHERE) ? 0.5 * sqrt(m0 * m0 + m1 * m1 + m2 * m2) : 0.5 * (fabs(m0) + fabs(m1) + fabs(m2));
+        h = h * 1.01 + 1e-3 + 1e-6 * fabs(c);
+        b.lo[a] = (float)(c - h);
+        b.hi[a] = (float)(c + h);
+    }
+    return b;
+}
+
+void build_bvh(const std::vector<Aabb> &boxes, std::vector<int> &idx, size_t lo, size_t hi, std::vector<ptd::BvhNode> &nodes)
+{
+    const size_t me = nodes.size();
+    nodes.push_back(ptd::BvhNode());
+    Aabb u = boxes[(size_t)idx[lo]];
+    float cmin[3], cmax[3];
+    for (int a = 0; a < 3; ++a) cmin[a] = cmax[a] = 0.5f * (u.lo[a] + u.hi[a]);
+    for (size_t k = lo + 1; k < hi; ++k) {
+        const Aabb &b = boxes[(size_t)idx[k]];
+        for (int a = 0; a < 3; ++a) {
+            if (b.lo[a] < u.lo[a]) u.lo[a] = b.lo[a];
+            if (b.hi[a] > u.hi[a]) u.hi[a] = b.hi[a];
+            const float cc = 0.5f * (b.lo[a] + b.hi[a]);
+            if (cc < cmin[a]) cmin[a] = cc;
+            if (cc > cmax[a]) cmax[a] = cc;
+        }
+    }
+    if (hi - lo == 1) {
+        nodes[me].prim = idx[lo];
+    } else {
+        int axis = 0;
+        for (int a = 1; a < 3; ++a) if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
+        const size_t mid = lo + (hi - lo) / 2;
+        std::nth_element(idx.begin() + (long)lo, idx.begin() + (long)mid, idx.begin() + (long)hi, [&](int x, int y) {
+            return boxes[(size_t)x].lo[axis] + boxes[(size_t)x].hi[axis] < boxes[(size_t)y].lo[axis] + boxes[(size_t)y].hi[axis];
+        });
+        nodes[me].prim = -1;
+        build_bvh(boxes, idx, lo, mid, nodes);
+        build_bvh(boxes, idx, mid, hi, nodes);
+    }
+    for (int a = 0; a < 3; ++a) { nodes[me].lo[a] = u.lo[a]; nodes[me].hi[a] = u.hi[a]; }
+    nodes[me].skip = (uint32_t)nodes.size();          // first node after this subtree
+}
 
 // (re)build everything that depends on scene, camera or options
 int configure(pt_ctx *c)
@@ -233,6 +289,42 @@ int configure(pt_ctx *c)
     }
     k.prims = c->d_prims;
     k.ro_eye = c->d_ro_eye;
+
+    // culling hierarchy (used by geom_path 4 / large scenes); MESH primitives have no geometry and stay out
+    {
+        std::vector<Aabb> boxes(c->geoms.size());
+        std::vector<int> idx;
+        float slo[3] = {0, 0, 0}, shi[3] = {0, 0, 0};
+        bool first_box = true;
+        for (size_t i = 0; i < c->geoms.size(); ++i) {
+            boxes[i] = prim_bounds(c->geoms[i]);
+            if (c->geoms[i].type == PT_MESH) continue;
+            for (int a = 0; a < 3; ++a) {
+                if (first_box || boxes[i].lo[a] < slo[a]) slo[a] = boxes[i].lo[a];
+                if (first_box || boxes[i].hi[a] > shi[a]) shi[a] = boxes[i].hi[a];
+            }
+            first_box = false;
+        }
+        float sext = 0.0f;
+        for (int a = 0; a < 3; ++a) if (shi[a] - slo[a] > sext) sext = shi[a] - slo[a];
+        k.nbig = 0;
+        for (size_t i = 0; i < c->geoms.size(); ++i) {
+            if (c->geoms[i].type == PT_MESH) continue;
+            float ext = 0.0f;
+            for (int a = 0; a < 3; ++a) if (boxes[i].hi[a] - boxes[i].lo[a] > ext) ext = boxes[i].hi[a] - boxes[i].lo[a];
+            // a primitive spanning > 40 % of the scene goes to the always-tested list (at most 16 of them)
+            if (ext > 0.4f * sext && k.nbig < 16 && c->geoms.size() > 16) k.big[k.nbig++] = (int)i;
+            else idx.push_back((int)i);
+        }
+        std::vector<ptd::BvhNode> nodes;
+        if (!idx.empty()) build_bvh(boxes, idx, 0, idx.size(), nodes);
+        k.nnodes = (int)nodes.size();
+        if (c->d_bvh) { (void)hipFree(c->d_bvh); c->d_bvh = nullptr; }
+        if (nodes.empty()) nodes.push_back(ptd::BvhNode());
+        HIP_TRY(hipMalloc((void **)&c->d_bvh, nodes.size() * sizeof(ptd::BvhNode)));
+        HIP_TRY(hipMemcpy(c->d_bvh, nodes.data(), nodes.size() * sizeof(ptd::BvhNode), hipMemcpyHostToDevice));
+        k.bvh = c->d_bvh;
+    }
     k.mats = c->d_mats;
 
     // framebuffer
@@ -255,7 +347,7 @@ int configure(pt_ctx *c)
     pt::LaunchCfg &cfg = c->cfg;
     cfg.workgroup = o.workgroup ? o.workgroup : 256;
     // library choice: the hit queue pays when most primitives are hit by some lane of every wave (small scenes)
-    cfg.geom = o.geom_path == 0 ? (k.nG <= 32 ? 2 : 0) : o.geom_path - 1;
+    cfg.geom = o.geom_path == 0 ? (k.nG <= 32 ? 2 : 3) : o.geom_path - 1;
     cfg.compact = o.compaction;
     k.cull = (k.nG > 32 && !getenv("PT_NO_CULL")) ? 1 : 0;
     k.nshard = (cfg.compact == 1) ? pt::NSHARD : 1;
@@ -408,6 +500,7 @@ void pt_destroy(pt_ctx *c)
     if (c->d_prims) (void)hipFree(c->d_prims);
     if (c->d_mats) (void)hipFree(c->d_mats);
     if (c->d_ro_eye) (void)hipFree(c->d_ro_eye);
+    if (c->d_bvh) (void)hipFree(c->d_bvh);
     if (c->d_image_own) (void)hipFree(c->d_image_own);
     if (c->d_pool) (void)hipFree(c->d_pool);
     if (c->d_lbuf) (void)hipFree(c->d_lbuf);
@@ -423,7 +516,7 @@ int pt_set_options(pt_ctx *c, const pt_options *o)
     const int wg = o->workgroup;
     if (!(wg == 0 || wg == 64 || wg == 128 || wg == 256 || wg == 512 || wg == 1024))
         return fail(PT_ERR_INVALID, "workgroup %d not one of 0,64,128,256,512,1024", wg);
-    if (o->geom_path < 0 || o->geom_path > 3) return fail(PT_ERR_INVALID, "geom_path %d not in 0..3", o->geom_path);
+    if (o->geom_path < 0 || o->geom_path > 4) return fail(PT_ERR_INVALID, "geom_path %d not in 0..4", o->geom_path);
     if (o->row_begin < 0 || o->row_end < o->row_begin) return fail(PT_ERR_INVALID, "tile rows [%d,%d)", o->row_begin, o->row_end);
     if (o->batch < 0 || o->batch > pt::PT_MAX_BATCH) return fail(PT_ERR_INVALID, "batch %d not in 0..%d", o->batch, pt::PT_MAX_BATCH);
     if (o->compaction < 0 || o->compaction > 2) return fail(PT_ERR_INVALID, "compaction %d not 0, 1 or 2", o->compaction);

@@ -102,6 +102,16 @@ struct Prim {
 };
 static_assert(sizeof(Prim) == 128, "Prim must be 128 B");
 
+// Node of the culling hierarchy used for large primitive lists: padded world-space box, depth-first order,
+// `skip` = index of the next node when this subtree is missed (so traversal needs no stack), prim >= 0 on leaves.
+struct BvhNode {
+    float lo[3];
+    uint32_t skip;
+    float hi[3];
+    int32_t prim;
+};
+static_assert(sizeof(BvhNode) == 32, "BvhNode must be 32 B");
+
 // Material planes (SoA): plane k of material id at mats[k * nM + id]
 enum { M_CR = 0, M_CG, M_CB, M_SR, M_SG, M_SB, M_REFL, M_REFR, M_IOR, M_EMIT, M_PLANES };
 

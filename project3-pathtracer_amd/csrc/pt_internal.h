@@ -51,6 +51,10 @@ struct KParams {
     int rr_start;
     uint32_t seed;
     const ptd::Prim *prims;
+    const ptd::BvhNode *bvh;   // culling hierarchy over the primitives (GEOM 3), depth-first with skip links
+    int nnodes;
+    int nbig;              // primitives too large to cull (walls...): tested by every ray before the walk
+    int big[16];           // their indices
     const float *ro_eye;   // per primitive: inverseTransform*(eye,1) as float4 (camera rays share their origin)
     const float *mats;     // M_PLANES planes of nM floats
     float *image;          // tile framebuffer, fp32 RGB packed (12 B/pixel)
@@ -66,7 +70,7 @@ struct KParams {
 struct LaunchCfg {
     int workgroup;   // 64..1024
     int grid;        // workgroups per bounce launch
-    int geom;        // 0 scalar direct, 1 LDS direct, 2 hit queue (pt_kernels.hip)
+    int geom;        // 0 scalar direct, 1 LDS direct, 2 hit queue, 3 per-lane hierarchy walk (pt_kernels.hip)
     int compact;     // 0 off, 1 per-wave sharded reservation, 2 workgroup scan + single counter
 };
 

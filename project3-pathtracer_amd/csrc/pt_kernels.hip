@@ -57,7 +57,11 @@ struct Hit {
 //                      point, distance) runs on full 64-candidate batches with every lane busy, whichever
 //                      ray or primitive a candidate belongs to.  Results flow back to the owning lane through
 //                      a 64-bit LDS atomic min on (distance bits, primitive index).
-enum { GEOM_SCALAR = 0, GEOM_LDS = 1, GEOM_QUEUE = 2 };
+//   3  hierarchy walk: for large primitive lists.  Every lane walks a bounding-box hierarchy of the primitives
+//                      (LDS-resident, depth-first with skip links, no stack) and runs the exact test only on the
+//                      leaves its ray can reach; per-lane primitive records are gathered from the LDS copy.  The
+//                      boxes are padded and only ever cull, so the nearest hit (ties -> lowest index) is unchanged.
+enum { GEOM_SCALAR = 0, GEOM_LDS = 1, GEOM_QUEUE = 2, GEOM_BVH = 3 };
 
 // Conservative cull for large primitive lists: true when NO lane of the wave can hit the primitive, judged by a
 // padded world-space bounding sphere (centre = transform*(0,0,0,1), radius^2 in the record).  It only ever skips
@@ -116,6 +120,74 @@ __device__ __forceinline__ Hit nearestHitDirect(const KParams &p, const Prim *s_
             h.p = ip;
             h.n = in;
             h.material = mat;
+        }
+    }
+    return h;
+}
+
+template <bool FIRST>
+__device__ __forceinline__ Hit nearestHitBvh(const KParams &p, const Prim *s_prims, const float4 *s_nodes, f3 o, f3 d)
+{
+    Hit h;
+    h.any = false;
+    h.material = 0;
+    h.p = mk(0, 0, 0);
+    h.n = mk(0, 0, 0);
+    float best_t = 0.0f;
+    uint32_t best_g = 0xFFFFFFFFu;
+    // reciprocal direction for the box slabs: culling only, so an approximate, finite value is enough
+    const float ix = __builtin_amdgcn_rcpf(fabsf(d.x) > 1e-20f ? d.x : (d.x < 0 ? -1e-20f : 1e-20f));
+    const float iy = __builtin_amdgcn_rcpf(fabsf(d.y) > 1e-20f ? d.y : (d.y < 0 ? -1e-20f : 1e-20f));
+    const float iz = __builtin_amdgcn_rcpf(fabsf(d.z) > 1e-20f ? d.z : (d.z < 0 ? -1e-20f : 1e-20f));
+    // primitives that span most of the scene (walls, big lights) would bloat every box above them: they are kept
+    // out of the hierarchy and tested by every ray, wave-uniformly through the scalar unit
+    for (int k = 0; k < p.nbig; ++k) {
+        const int g = p.big[k];
+        const Prim P = load_prim_scalar(p.prims, g);
+        f3 ip, in;
+        const float t = intersectPrim<FIRST>(P, o, d, FIRST ? load_ro_eye(p.ro_eye, g) : o, ip, in);
+        if (t > 0 && (!h.any || t < best_t || (t == best_t && (uint32_t)g < best_g))) {
+            h.any = true;
+            best_t = t;
+            best_g = (uint32_t)g;
+            h.p = ip;
+            h.n = in;
+            h.material = P.material;
+        }
+    }
+    uint32_t i = 0;
+    const uint32_t nn = (uint32_t)p.nnodes;
+    for (;;) {
+        // walk to the next leaf this ray can reach (box tests only), so that the lanes of the wave then run the
+        // long exact test together instead of one lane at a time
+        int prim = -1;
+        while (i < nn) {
+            const float4 a = s_nodes[2 * i], b = s_nodes[2 * i + 1];
+            const float x0 = (a.x - o.x) * ix, x1 = (b.x - o.x) * ix;
+            const float y0 = (a.y - o.y) * iy, y1 = (b.y - o.y) * iy;
+            const float z0 = (a.z - o.z) * iz, z1 = (b.z - o.z) * iz;
+            const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+            const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+            // miss, or the box starts beyond the current best hit (with slack for |d| != 1 and rounding)
+            if (!(tn <= tf) || (h.any && tn * 0.999f - 1e-3f > best_t)) {
+                i = __float_as_uint(a.w);
+                continue;
+            }
+            i = i + 1u;
+            prim = (int)__float_as_uint(b.w);
+            if (prim >= 0) break;
+        }
+        if (prim < 0) break;
+        const Prim &P = s_prims[prim];                     // per-lane gather from the LDS copy
+        f3 ip, in;
+        const float t = intersectPrim<false>(P, o, d, o, ip, in);
+        if (t > 0 && (!h.any || t < best_t || (t == best_t && (uint32_t)prim < best_g))) {
+            h.any = true;
+            best_t = t;
+            best_g = (uint32_t)prim;
+            h.p = ip;
+            h.n = in;
+            h.material = P.material;
         }
     }
     return h;
@@ -235,12 +307,14 @@ template <int WG, bool FIRST, int GEOM, int COMPACT>
 __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce)
 {
     constexpr int NW = WG / 64;
-    constexpr bool PRIMS_IN_LDS = (GEOM != GEOM_SCALAR);
+    constexpr bool PRIMS_IN_LDS = (GEOM == GEOM_LDS || GEOM == GEOM_QUEUE);   // GEOM_BVH gathers records from global memory (L1/L2)
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     // LDS carve: [prims nG*128 B (GEOM 1,2)] [per-wave hit queues (GEOM 2)] [material planes] [scan scratch]
     Prim *s_prims = reinterpret_cast<Prim *>(smem);
     const int prim_bytes = PRIMS_IN_LDS ? p.nG * (int)sizeof(Prim) : 0;
-    unsigned char *s_queue = smem + prim_bytes;
+    const float4 *s_nodes = reinterpret_cast<const float4 *>(smem + prim_bytes);
+    const int node_bytes = (GEOM == GEOM_BVH) ? p.nnodes * (int)sizeof(BvhNode) : 0;
+    unsigned char *s_queue = smem + prim_bytes + node_bytes;
     const int queue_bytes = (GEOM == GEOM_QUEUE) ? NW * (int)WAVE_QUEUE_BYTES : 0;
     float *s_mats = reinterpret_cast<float *>(s_queue + queue_bytes);
     const int mat_words = (p.nM * M_PLANES + 3) & ~3;
@@ -263,6 +337,11 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
         const uint4 *src = reinterpret_cast<const uint4 *>(p.prims);
         uint4 *dst = reinterpret_cast<uint4 *>(s_prims);
         for (int k = tid; k < p.nG * 8; k += WG) dst[k] = src[k];
+    }
+    if (GEOM == GEOM_BVH) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.bvh);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem + prim_bytes);
+        for (int k = tid; k < p.nnodes * 2; k += WG) dst[k] = src[k];
     }
     for (int k = tid; k < p.nM * M_PLANES; k += WG) s_mats[k] = p.mats[k];
     __syncthreads();
@@ -361,9 +440,12 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
         Hit h;
         if (GEOM == GEOM_QUEUE) {
             h = nearestHitQueued<FIRST>(p, s_prims, wq, o, d, valid, (uint32_t)lane);   // whole wave, see above
+        } else if (GEOM == GEOM_BVH) {
+            h.any = false;
+            if (valid) h = nearestHitBvh<FIRST>(p, p.prims, s_nodes, o, d);
         } else {
             h.any = false;
-            if (valid) h = nearestHitDirect<GEOM, FIRST>(p, s_prims, o, d);
+            if (valid) h = nearestHitDirect<(GEOM == GEOM_LDS ? GEOM_LDS : GEOM_SCALAR), FIRST>(p, s_prims, o, d);
         }
         if (valid) {
             f3 L = mk(0, 0, 0);
@@ -653,8 +735,9 @@ __global__ __launch_bounds__(256) void k_send_image_to_pbo(pt_uchar4 *pbo, const
 // ---------------------------------------------------------------------------------------------
 size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg)
 {
-    size_t prim = cfg.geom != GEOM_SCALAR ? (size_t)p.nG * sizeof(Prim) : 0;
+    size_t prim = (cfg.geom == GEOM_LDS || cfg.geom == GEOM_QUEUE) ? (size_t)p.nG * sizeof(Prim) : 0;
     size_t queue = cfg.geom == GEOM_QUEUE ? (size_t)(cfg.workgroup / 64) * WAVE_QUEUE_BYTES : 0;
+    if (cfg.geom == GEOM_BVH) prim += (size_t)p.nnodes * sizeof(BvhNode);
     size_t mats = (size_t)((p.nM * M_PLANES + 3) & ~3) * sizeof(float);
     size_t scan = (size_t)(2 * (cfg.workgroup / 64) + 2) * sizeof(uint32_t);
     static const size_t extra = getenv("PT_EXTRA_LDS") ? (size_t)atol(getenv("PT_EXTRA_LDS")) : 0;   // occupancy experiments
@@ -678,6 +761,7 @@ static const void *bounce_fn_geom(bool first, int compact)
 template <int WG>
 static const void *bounce_fn_wg(bool first, int geom, int compact)
 {
+    if (geom == GEOM_BVH) return bounce_fn_geom<WG, GEOM_BVH>(first, compact);
     if (geom == GEOM_QUEUE) return bounce_fn_geom<WG, GEOM_QUEUE>(first, compact);
     if (geom == GEOM_LDS) return bounce_fn_geom<WG, GEOM_LDS>(first, compact);
     return bounce_fn_geom<WG, GEOM_SCALAR>(first, compact);

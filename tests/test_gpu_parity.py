@@ -112,13 +112,14 @@ def test_cloud_256_primitives(pkg):
 
 
 @pytest.mark.parametrize("rotat", [0, 1])
-def test_cloud_cull_is_conservative(pkg, rotat):
-    """Large primitive lists are culled per wave with padded bounding spheres; the cull may only skip primitives no
-    lane can hit, so a bigger sample of the 256-primitive scene must still match the oracle bit for bit
-    (a wrongly culled hit shows up as an O(1) pixel error)."""
-    g, lg, _ = gpu_render(pkg, "cloud256.txt", 384, 216, 8, iters=2, rotat=rotat)
+@pytest.mark.parametrize("geom_path", [1, 4])
+def test_cloud_cull_is_conservative(pkg, rotat, geom_path):
+    """Large primitive lists are culled (geom_path 1: per wave with padded bounding spheres; 4: per lane with a
+    padded bounding-box hierarchy).  Culling may only skip primitives that cannot be hit, so a bigger sample of
+    the 256-primitive scene must still match the oracle bit for bit (a wrongly culled hit is an O(1) pixel error)."""
+    g, lg, _ = gpu_render(pkg, "cloud256.txt", 384, 216, 8, iters=2, rotat=rotat, geom_path=geom_path)
     c, lc = cpu_render("cloud256.txt", 384, 216, 8, iters=2, rotat=rotat)
-    check(g, c, lg, lc, f"cloud256 cull rotat={rotat}")
+    check(g, c, lg, lc, f"cloud256 cull rotat={rotat} geom_path={geom_path}")
 
 
 def test_seed_changes_image(pkg):
@@ -201,11 +202,13 @@ def test_geometry_paths_identical(pkg):
     a, la, _ = gpu_render(pkg, "cloud256.txt", 128, 72, 4, geom_path=1, rotat=1)
     b, lb, _ = gpu_render(pkg, "cloud256.txt", 128, 72, 4, geom_path=2, rotat=1)
     c, lc, _ = gpu_render(pkg, "cloud256.txt", 128, 72, 4, geom_path=3, rotat=1)
+    d, ld, _ = gpu_render(pkg, "cloud256.txt", 128, 72, 4, geom_path=4, rotat=1)
     assert np.array_equal(a, b) and la == lb
     assert np.array_equal(a, c) and la == lc
+    assert np.array_equal(a, d) and la == ld
 
 
-@pytest.mark.parametrize("geom_path", [0, 1, 2, 3])
+@pytest.mark.parametrize("geom_path", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("scene,depth,rotat", [("sampleScene.txt", 6, 0), ("cornell_glass.txt", 10, 1),
                                                ("cloud256.txt", 5, 1)])
 def test_every_geometry_path_against_oracle(pkg, geom_path, scene, depth, rotat):
@@ -410,7 +413,7 @@ def test_random_scenes_bit_exact(pkg, seed):
     ma = (O.Material * len(mats))(*mats)
     cam = O.make_camera(W, H, eye, view, up, fovy)
     ref, live = O.render(ga, len(geoms), ma, len(mats), cam, depth, iters=iters, rr_start=3, seed=seed)
-    for geom_path in (1, 3) if n_prims <= 32 else (1, 2):
+    for geom_path in (1, 3, 4) if n_prims <= 32 else (1, 2, 4):
         with pkg.Renderer(0) as r:
             r.set_options(depth=depth, rr_start=3, seed=seed, geom_path=geom_path)
             r.set_scene(C.cast(ga, C.POINTER(pkg.StaticGeom)), len(geoms), C.cast(ma, C.POINTER(pkg.Material)), len(mats))
