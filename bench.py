@@ -228,7 +228,7 @@ def main():
                             f"{args.depth} bounces, diffuse+specular, rotat={args.rotat}, rr_start={args.rr_start}",
                 "scene": args.scene, "width": W, "height": Hfull, "depth": args.depth, "spp": args.steps,
                 "rotat_units": args.rotat, "primitives": sc.n_objects, "materials": sc.n_materials,
-                "compaction": 0 if args.no_compaction else args.compaction, "iteration_batch": args.batch or 4, "hip_graph": not args.no_graph,
+                "compaction": 0 if args.no_compaction else args.compaction, "iteration_batch": args.batch or 8, "hip_graph": not args.no_graph,
                 "parallelism": f"pixel-bands x{world}" + (", 1 RCCL gather" if world > 1 else ""),
             },
             "ray_bounces": int(rb_total),

@@ -25,7 +25,7 @@ using namespace ptd;
 
 static constexpr uint32_t DEAD = 0xFFFFFFFFu;
 static constexpr bool DEBUG_CULL = false;
-static constexpr int MAXSLOT = 4;                 // iterations in flight per launch sequence (pt_internal.h PT_MAX_BATCH)
+static constexpr int MAXSLOT = 8;                 // iterations in flight per launch sequence (pt_internal.h PT_MAX_BATCH)
 static constexpr uint32_t SLOT_SHIFT = 28;        // pixel word = tile-local pixel | slot << 28
 static constexpr uint32_t PIX_MASK = (1u << SLOT_SHIFT) - 1u;
 
@@ -400,13 +400,17 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
         if (FIRST) {
             if (valid) {
                 // raycastFromCameraKernel: jittered pinhole ray through tile-local pixel pl of iteration slot
-                const uint32_t slot = (i >= npix ? 1u : 0u) + (i >= 2u * npix ? 1u : 0u) + (i >= 3u * npix ? 1u : 0u);
+                uint32_t slot = 0;
+#pragma unroll
+                for (uint32_t k = 1; k < (uint32_t)MAXSLOT; ++k) slot += (i >= k * npix) ? 1u : 0u;
                 const uint32_t pl = i - slot * npix;
                 pix = pl | (slot << SLOT_SHIFT);
                 const uint32_t gp = pl + p.pix_offset;
                 const uint32_t x = pl % (uint32_t)p.W;
                 const uint32_t y = (uint32_t)p.row_begin + pl / (uint32_t)p.W;
-                const uint32_t kc = slot == 0u ? key_cam[0] : slot == 1u ? key_cam[1] : slot == 2u ? key_cam[2] : key_cam[3];
+                uint32_t kc = key_cam[0];
+#pragma unroll
+                for (uint32_t k = 1; k < (uint32_t)MAXSLOT; ++k) kc = (slot == k) ? key_cam[k] : kc;
                 uint32_t s = minstd_seed(wang_hash(gp ^ kc));
                 s = minstd_next(s);
                 const float jx = u01_of(s);
@@ -458,7 +462,9 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
                 } else if (!last) {
                     // calculateBSDF: pick the lobe, build the next ray
                     const uint32_t slot = pix >> SLOT_SHIFT;
-                    const uint32_t kb = slot == 0u ? key_bounce[0] : slot == 1u ? key_bounce[1] : slot == 2u ? key_bounce[2] : key_bounce[3];
+                    uint32_t kb = key_bounce[0];
+#pragma unroll
+                    for (uint32_t k = 1; k < (uint32_t)MAXSLOT; ++k) kb = (slot == k) ? key_bounce[k] : kb;
                     uint32_t s = minstd_seed(wang_hash(((pix & PIX_MASK) + p.pix_offset) ^ kb));
                     s = minstd_next(s);
                     const float u_select = u01_of(s);

@@ -138,14 +138,14 @@ def test_multi_iteration_running_mean(pkg):
     assert st.iterations == 6
 
 
-@pytest.mark.parametrize("batch", [1, 2, 3, 4])
+@pytest.mark.parametrize("batch", [1, 2, 3, 4, 5, 8])
 def test_iteration_batching_is_invisible(pkg, batch):
-    """1..4 iterations in flight per launch sequence; samples are folded in iteration order, so the running
+    """1..8 iterations in flight per launch sequence; samples are folded in iteration order, so the running
     mean is the same bits, also when the iteration count is not a multiple of the batch."""
-    g, lg, st = gpu_render(pkg, "sampleScene_spec.txt", 121, 67, 5, iters=7, batch=batch, rr_start=2)
-    c, lc = cpu_render("sampleScene_spec.txt", 121, 67, 5, iters=7, rr_start=2)
+    g, lg, st = gpu_render(pkg, "sampleScene_spec.txt", 121, 67, 5, iters=11, batch=batch, rr_start=2)
+    c, lc = cpu_render("sampleScene_spec.txt", 121, 67, 5, iters=11, rr_start=2)
     check(g, c, lg, lc, f"batch={batch}")
-    assert st.iterations == 7
+    assert st.iterations == 11
 
 
 def test_resume_from_host_image(pkg):
