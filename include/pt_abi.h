@@ -128,6 +128,7 @@ int  pt_set_stream(pt_ctx *ctx, void *hip_stream);    /* render on a caller-owne
 size_t pt_image_bytes(pt_ctx *ctx);
 int  pt_bind_image(pt_ctx *ctx, void *device_rgb);    /* render into caller-owned device memory (>= pt_image_bytes);
                                                          NULL = library-owned buffer */
+int  pt_image_device_pointer(pt_ctx *ctx, void **device_rgb_out);   /* where the tile's framebuffer lives on the device */
 int  pt_clear_image(pt_ctx *ctx);                     /* clearImage, ref: src/raytraceKernel.cu:48-55 */
 int  pt_upload_image(pt_ctx *ctx, const float *host_rgb);    /* H2D, ref: src/raytraceKernel.cu:120 */
 int  pt_download_image(pt_ctx *ctx, float *host_rgb);        /* D2H (synchronous), ref: src/raytraceKernel.cu:154 */
@@ -191,6 +192,27 @@ int  pt_scene_get_frame(const pt_scene *s, int frame, pt_static_geom *geoms_out,
                         pt_camera_data *camera_out);
 /* RES override: recomputes fov.x from fov.y as the loader does (ref: src/scene.cpp:204-207) */
 int  pt_camera_set_resolution(pt_camera_data *cam, int width, int height);
+
+/* ---- several devices of one node behind one handle (single process): device k renders the k-th band of rows,
+ *      no communication while rendering, bands gathered to the host or to one device over xGMI peer copies.
+ *      `devices` may name a device more than once (each entry gets its own context). ---- */
+typedef struct pt_multi pt_multi;
+int  pt_multi_create(const int *devices, int n, pt_multi **out);
+void pt_multi_destroy(pt_multi *m);
+int  pt_multi_count(const pt_multi *m);
+int  pt_multi_set_options(pt_multi *m, const pt_options *opt);      /* row_begin/row_end are set per band */
+int  pt_multi_set_scene(pt_multi *m, const pt_static_geom *geoms, int numberOfGeoms,
+                        const pt_material *materials, int numberOfMaterials);
+int  pt_multi_set_camera(pt_multi *m, const pt_camera_data *cam);
+int  pt_multi_band(const pt_multi *m, int k, int *row_begin, int *row_end);
+int  pt_multi_clear_image(pt_multi *m);
+int  pt_multi_upload_image(pt_multi *m, const float *host_rgb_full_frame);
+int  pt_multi_render(pt_multi *m, int iter_first, int iter_count);  /* asynchronous on every device */
+int  pt_multi_synchronize(pt_multi *m);
+int  pt_multi_download_image(pt_multi *m, float *host_rgb_full_frame);
+int  pt_multi_gather_to_device(pt_multi *m, void *device_rgb_full_frame, int dst_device);
+int  pt_multi_send_image_to_pbo(pt_multi *m, pt_uchar4 *device_pbo);  /* single-device handles only */
+int  pt_multi_get_stats(pt_multi *m, pt_stats *out);                /* sums over devices (gpu_ms: max) */
 
 /* ---- end-of-render image write-out (ref: src/main.cpp:116-141, src/image.cpp:41-88): horizontal flip
  *      buffer (x,y) -> picture (W-1-x, y), gamma 1.0, clamp(v*255, 0, 255) truncation ---- */

@@ -120,6 +120,22 @@ def lib():
         "pt_image_bytes": (sz, [vp]),
         "pt_bind_image": (i, [vp, vp]),
         "pt_clear_image": (i, [vp]),
+        "pt_image_device_pointer": (i, [vp, P(vp)]),
+        "pt_multi_create": (i, [P(i), i, P(vp)]),
+        "pt_multi_destroy": (None, [vp]),
+        "pt_multi_count": (i, [vp]),
+        "pt_multi_set_options": (i, [vp, P(Options)]),
+        "pt_multi_set_scene": (i, [vp, P(StaticGeom), i, P(Material), i]),
+        "pt_multi_set_camera": (i, [vp, P(CameraData)]),
+        "pt_multi_band": (i, [vp, i, P(i), P(i)]),
+        "pt_multi_clear_image": (i, [vp]),
+        "pt_multi_upload_image": (i, [vp, vp]),
+        "pt_multi_render": (i, [vp, i, i]),
+        "pt_multi_synchronize": (i, [vp]),
+        "pt_multi_download_image": (i, [vp, vp]),
+        "pt_multi_gather_to_device": (i, [vp, vp, i]),
+        "pt_multi_send_image_to_pbo": (i, [vp, vp]),
+        "pt_multi_get_stats": (i, [vp, P(Stats)]),
         "pt_upload_image": (i, [vp, vp]),
         "pt_download_image": (i, [vp, vp]),
         "pt_render": (i, [vp, i, i]),

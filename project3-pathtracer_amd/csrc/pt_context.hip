@@ -590,6 +590,15 @@ int pt_bind_image(pt_ctx *c, void *device_rgb)
     return PT_OK;
 }
 
+int pt_image_device_pointer(pt_ctx *c, void **out)
+{
+    if (!c || !out) return fail(PT_ERR_INVALID, "pt_image_device_pointer: NULL argument");
+    int rc = configure(c);
+    if (rc != PT_OK) return rc;
+    *out = image_ptr(c);
+    return PT_OK;
+}
+
 int pt_clear_image(pt_ctx *c)
 {
     if (!c) return fail(PT_ERR_INVALID, "pt_clear_image: NULL context");

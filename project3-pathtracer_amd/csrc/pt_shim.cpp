@@ -12,7 +12,8 @@
 //   PT_DEPTH (8)          bounces per path (the reference's traceDepth, src/raytraceKernel.cu:110)
 //   PT_RR_START (-1)      first bounce with Russian roulette, -1 = off
 //   PT_SEED (0)           RNG stream selector
-//   PT_DEVICE (0)         HIP device
+//   PT_DEVICES (0)        comma-separated HIP devices; with several, each renders a band of rows of the frame
+//                         (pt_multi_*), the bands are gathered into renderCam->image; PBO output then needs 1 device
 //   PT_SHIM_BATCH (4)     iterations that may be pending inside the shim before they are rendered together
 //                         (only while nobody can observe them: no PBO, no read-back due); 1 = render every call
 //   PT_READBACK_EVERY (0) also copy the image back every N iterations (0 = only on the last one,
@@ -30,7 +31,8 @@
 namespace {
 
 struct ShimState {
-    pt_ctx *ctx = nullptr;
+    pt_multi *ctx = nullptr;
+    int ndev = 1;
     std::vector<pt_static_geom> geoms;
     std::vector<pt_material> mats;
     pt_camera_data cam;
@@ -60,7 +62,7 @@ void check(int rc, const char *msg)
 // pt_render call, so that the renderer can keep several of them in flight (pt_options.batch).
 void flush_pending()
 {
-    if (g.pend_count > 0) check(pt_render(g.ctx, g.pend_first, g.pend_count), "pt_render");
+    if (g.pend_count > 0) check(pt_multi_render(g.ctx, g.pend_first, g.pend_count), "pt_render");
     g.pend_count = 0;
 }
 
@@ -70,13 +72,24 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
                       int numberOfMaterials, geom *geoms, int numberOfGeoms)
 {
     if (!g.ctx) {
-        check(pt_create(env_int("PT_DEVICE", 0), &g.ctx), "pt_create");
+        std::vector<int> devs;
+        const char *dl = getenv("PT_DEVICES");
+        if (dl && *dl) {
+            for (const char *q = dl; *q;) {
+                devs.push_back(atoi(q));
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+        }
+        if (devs.empty()) devs.push_back(env_int("PT_DEVICE", 0));
+        g.ndev = (int)devs.size();
+        check(pt_multi_create(devs.data(), g.ndev, &g.ctx), "pt_create");
         pt_options o;
         pt_default_options(&o);
         o.depth = env_int("PT_DEPTH", o.depth);
         o.rr_start = env_int("PT_RR_START", o.rr_start);
         o.seed = (unsigned)env_int("PT_SEED", 0);
-        check(pt_set_options(g.ctx, &o), "pt_set_options");
+        check(pt_multi_set_options(g.ctx, &o), "pt_set_options");
         g.readback_every = env_int("PT_READBACK_EVERY", 0);
         g.defer = env_int("PT_SHIM_BATCH", 4);
         if (g.defer < 1) g.defer = 1;
@@ -106,7 +119,7 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
         (!mats.empty() && memcmp(mats.data(), g.mats.data(), mats.size() * sizeof(pt_material)) != 0);
     if (scene_changed) {
         flush_pending();                       // pending iterations belong to the previous scene
-        check(pt_set_scene(g.ctx, list.data(), numberOfGeoms, mats.data(), numberOfMaterials), "pt_set_scene");
+        check(pt_multi_set_scene(g.ctx, list.data(), numberOfGeoms, mats.data(), numberOfMaterials), "pt_set_scene");
         g.geoms = list;
         g.mats = mats;
     }
@@ -121,7 +134,7 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
     cam.fov = {renderCam->fov.x, renderCam->fov.y};
     if (!g.have_cam || memcmp(&cam, &g.cam, sizeof cam) != 0) {
         flush_pending();
-        check(pt_set_camera(g.ctx, &cam), "pt_set_camera");
+        check(pt_multi_set_camera(g.ctx, &cam), "pt_set_camera");
         g.cam = cam;
         g.have_cam = true;
     }
@@ -133,16 +146,19 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
     const bool readback = host_image && (last || (g.readback_every > 0 && iterations % g.readback_every == 0));
     if (iterations != g.last_iteration + 1) {
         flush_pending();                       // not the continuation of what is pending
-        if (iterations > 1 && host_image) check(pt_upload_image(g.ctx, host_image), "pt_upload_image");
+        if (iterations > 1 && host_image) check(pt_multi_upload_image(g.ctx, host_image), "pt_upload_image");
     }
     if (g.pend_count == 0) g.pend_first = iterations;
     g.pend_count++;
     g.last_iteration = iterations;
     if (PBOpos || readback || g.pend_count >= g.defer) {
         flush_pending();
-        if (PBOpos) check(pt_send_image_to_pbo(g.ctx, reinterpret_cast<pt_uchar4 *>(PBOpos)), "pt_send_image_to_pbo");
-        if (readback) check(pt_download_image(g.ctx, host_image), "pt_download_image");
+        if (PBOpos) {
+            if (g.ndev != 1) { fprintf(stderr, "Cuda error: PBO output needs a single device (PT_DEVICES): %d given.\n", g.ndev); exit(EXIT_FAILURE); }
+            check(pt_multi_send_image_to_pbo(g.ctx, reinterpret_cast<pt_uchar4 *>(PBOpos)), "pt_send_image_to_pbo");
+        }
+        if (readback) check(pt_multi_download_image(g.ctx, host_image), "pt_download_image");
         // make certain the kernels have completed (ref: src/raytraceKernel.cu:162-164)
-        check(pt_synchronize(g.ctx), "Kernel failed!");
+        check(pt_multi_synchronize(g.ctx), "Kernel failed!");
     }
 }

@@ -78,3 +78,20 @@ def test_headless_renders_every_animation_frame(tmp_path):
         assert np.array_equal(got, q), f"frame {frame}"
     frames = [read_bmp(os.path.join(tmp_path, f"anim.{f}.bmp")) for f in range(3)]
     assert not np.array_equal(frames[0], frames[1]) and not np.array_equal(frames[1], frames[2])
+
+
+def test_headless_on_several_contexts(tmp_path):
+    """PT_DEVICES=0,0,0: the shim shards the frame into row bands (one context each); same picture."""
+    pkg = load_package()
+    W, H, depth, iters = 90, 50, 4, 5
+    scene = os.path.join(ROOT, "scenes", "sampleScene_spec.txt")
+    env = dict(os.environ, PT_DEPTH=str(depth), PT_DEVICES="0,0,0")
+    res = subprocess.run([pkg.HEADLESS_PATH, f"scene={scene}", "frame=0", f"res={W}x{H}", f"iterations={iters}",
+                          f"out={tmp_path}"], env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    got = read_bmp(os.path.join(tmp_path, "spec.0.bmp"))
+    sc = O.LoadedScene(scene)
+    sc.set_resolution(W, H)
+    ref, _ = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, depth, iters=iters)
+    q = np.clip(ref * np.float32(255.0), 0, 255).astype(np.uint8)[:, ::-1, :]
+    assert np.array_equal(got, q)

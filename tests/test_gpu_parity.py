@@ -423,3 +423,54 @@ def test_random_scenes_bit_exact(pkg, seed):
             img = r.download_image()
             st = r.stats()
         check(img, ref, [int(x) for x in st.live_in[:depth]], [int(x) for x in live], f"random scene {seed} geom_path={geom_path}")
+
+
+# ---------------------------------------------------------------- several contexts behind one handle (pt_multi_*)
+@pytest.mark.parametrize("ndev", [1, 2, 3])
+def test_multi_device_handle_matches_single_context(pkg, ndev):
+    """pt_multi_*: row bands on `ndev` contexts (all on device 0 here; one per GPU on a real node), gathered to the
+    host and to one device buffer: identical to the single-context frame, counters add up."""
+    import torch
+    L = pkg.lib()
+    W, H, depth, iters = 144, 81, 5, 3
+    sc = pkg.SceneFile(os.path.join(SCENES, "sampleScene_spec.txt"))
+    sc.set_resolution(W, H)
+    ref, lr, _ = gpu_render(pkg, "sampleScene_spec.txt", W, H, depth, iters=iters)
+    devs = (C.c_int * ndev)(*([0] * ndev))
+    m = C.c_void_p()
+    assert L.pt_multi_create(devs, ndev, C.byref(m)) == 0
+    try:
+        o = pkg.Options()
+        L.pt_default_options(C.byref(o))
+        o.depth = depth
+        assert L.pt_multi_set_options(m, C.byref(o)) == 0
+        assert L.pt_multi_set_scene(m, sc.geoms, sc.n_objects, sc.mats, sc.n_materials) == 0
+        assert L.pt_multi_set_camera(m, C.byref(sc.camera)) == 0
+        assert L.pt_multi_count(m) == ndev
+        rows = []
+        for k in range(ndev):
+            r0, r1 = C.c_int(), C.c_int()
+            assert L.pt_multi_band(m, k, C.byref(r0), C.byref(r1)) == 0
+            rows.append((r0.value, r1.value))
+        assert rows[0][0] == 0 and rows[-1][1] == H and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+        assert L.pt_multi_clear_image(m) == 0
+        assert L.pt_multi_render(m, 1, iters) == 0
+        assert L.pt_multi_synchronize(m) == 0
+        host = np.zeros((H, W, 3), dtype=np.float32)
+        assert L.pt_multi_download_image(m, host.ctypes.data) == 0
+        assert np.array_equal(host, ref)
+        dev = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+        assert L.pt_multi_gather_to_device(m, dev.data_ptr(), 0) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(dev.cpu().numpy(), ref)
+        st = pkg.Stats()
+        assert L.pt_multi_get_stats(m, C.byref(st)) == 0
+        assert [int(x) for x in st.live_in[:depth]] == lr and st.iterations == iters
+        # resume from a host frame: upload, render the next iterations, same as rendering them in one go
+        assert L.pt_multi_upload_image(m, host.ctypes.data) == 0
+        assert L.pt_multi_render(m, iters + 1, 2) == 0
+        assert L.pt_multi_download_image(m, host.ctypes.data) == 0
+        ref5, _, _ = gpu_render(pkg, "sampleScene_spec.txt", W, H, depth, iters=iters + 2)
+        assert np.array_equal(host, ref5)
+    finally:
+        L.pt_multi_destroy(m)
