@@ -70,7 +70,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", default="r01")
     ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=8)      # one full batch, so every counted launch is a full-batch launch
     ap.add_argument("--passes", default="trace,sq1,sq2,sq3,fetch,write,tcc")
     ap.add_argument("bench_args", nargs="*")
     a = ap.parse_args()
@@ -78,13 +78,16 @@ def main():
     os.makedirs(out, exist_ok=True)
     bench = ["python3", os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup", str(a.warmup),
              "--no-cpu-baseline", "--traffic-json", "/nonexistent"] + a.bench_args
-    summary = {"tag": a.tag, "bench_cmd": " ".join(bench[1:]), "kernels": {}}
+    # the kernel-trace pass times bench.py's DEFAULT run (the command the driver runs, minus the CPU leg), so its
+    # average k_bounce duration is comparable with roofline.avg_launch_ms of the committed bench line
+    bench_trace = ["python3", os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + a.bench_args
+    summary = {"tag": a.tag, "bench_cmd": " ".join(bench[1:]), "trace_cmd": " ".join(bench_trace[1:]), "kernels": {}}
 
     for p in a.passes.split(","):
         d = os.path.join(out, p)
         os.makedirs(d, exist_ok=True)
         if p == "trace":
-            cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", p, "--"] + bench
+            cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", p, "--"] + bench_trace
         else:
             cmd = ["rocprofv3", "--pmc"] + PASSES[p] + ["--output-format", "csv", "-d", d, "-o", p, "--"] + bench
         res = run(cmd)
@@ -97,7 +100,7 @@ def main():
                 if line.startswith("{"):
                     try:
                         j = json.loads(line)
-                        summary["bench_under_trace"] = {k: j[k] for k in ("value", "ms_per_step", "roofline")}
+                        summary["bench_under_trace"] = {k: j[k] for k in ("value", "steps", "warmup", "ms_per_step", "roofline")}
                     except Exception:
                         pass
             for fn in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
@@ -154,6 +157,10 @@ def main():
         v, _ = total(c)
         if v and wc:
             der[c + "_over_WAVE_CYCLES"] = v / wc
+    kb, kf = summary["kernels"].get("k_bounce", {}), summary["kernels"].get("k_bounce<first>", {})
+    if kb.get("calls") and kf.get("calls"):
+        der["trace_avg_launch_ms"] = (kb["total_ms"] + kf["total_ms"]) / (kb["calls"] + kf["calls"])
+        der["trace_launches"] = kb["calls"] + kf["calls"]
     summary["k_bounce_derived"] = der
     if "hbm_bytes_per_launch" in der:
         summary["traffic_for_bench"] = {"hbm_bytes_per_launch": der["hbm_bytes_per_launch"], "source": f"pmc_{a.tag}"}
