@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_PEAK_TFLOPS = 157.3  # fp32 vector peak (FMA = 2 flops), same guide / SURVEY 8(d)
 
 
 def parse():
@@ -255,6 +256,14 @@ def main():
                         "VALU/latency-bound, see DESIGN.md",
             },
         }
+        # the physically binding roof is fp32 VALU issue; flops per ray-bounce = 95*nG + 150
+        # (nominal count of the intersection + shading arithmetic), peak = 157.3 TFLOP/s (FMA counted as 2 flops).
+        # The path's arithmetic is mul/add without contraction (bit parity), so at most half of that peak is
+        # reachable by construction.
+        flops_rb = 95 * sc.n_objects + 150
+        valu_tflops = sum(p_live) * flops_rb / (p_ms * 1e-3) / 1e12
+        out["valu_roofline"] = {"bound": "valu_fp32", "achieved": valu_tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": valu_tflops / VALU_PEAK_TFLOPS, "flops_per_ray_bounce": flops_rb}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, scene_path, rotat)
         print(json.dumps(out), flush=True)

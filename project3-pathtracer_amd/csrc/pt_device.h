@@ -74,7 +74,9 @@ __device__ __forceinline__ float rcp_rn(float x)                       // == 1.0
 }
 __device__ __forceinline__ float rsqrt_rn(float s)                     // == 1.0f / sqrtf(s) for every s
 {
-    const bool ok = s >= 0x1p-96f && s < 0x1p250f;                     // then sqrt(s) is in rcp_core's range
+    // 2^-96 <= s < +inf (then sqrt(s) is in rcp_core's range), as one unsigned compare on the bit pattern:
+    // negative numbers and NaNs wrap around to the top of the range and fail it
+    const bool ok = (__float_as_uint(s) - 0x0F800000u) < (0x7F800000u - 0x0F800000u);
     if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) return rcp_core(sqrt_core(s));
     return 1.0f / sqrtf(s);
 }
@@ -209,10 +211,38 @@ __device__ __forceinline__ bool candidateT(uint32_t type, const float *inv, f3 o
         float firstTerm = -vDot;
         float t1 = firstTerm + squareRoot;
         float t2 = firstTerm - squareRoot;
-        if (t1 < 0 && t2 < 0) return false;
-        else if (t1 > 0 && t2 > 0) t = (t2 < t1) ? t2 : t1;
-        else t = (t1 < t2) ? t2 : t1;
+        // ref lines 98-106: both negative -> miss; both positive -> min; otherwise max.  squareRoot >= 0 and rounding
+        // is monotonic, so t2 <= t1 always and the three-way test collapses to this (same result for every input,
+        // NaN included: then every compare is false on both forms and t = t1)
+        if (t1 < 0) return false;
+        t = (t2 > 0) ? t2 : t1;
         return true;
+    }
+    // Slab test.  Usual case (every lane's direction components normal and < 2^126, tested once per wave): exact
+    // short reciprocals, min/max instead of compare+select pairs, entry/exit face found by equality afterwards.
+    // Identical to the reference form below whenever no slab distance is NaN, which needs a zero direction
+    // component -- excluded here -- or a non-finite ray.
+    {
+        const float ax = fabsf(rd.x), ay = fabsf(rd.y), az = fabsf(rd.z);
+        const bool ok = fminf(fminf(ax, ay), az) >= 0x1p-126f && fmaxf(fmaxf(ax, ay), az) < 0x1p126f;
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
+            const float ix = rcp_core(rd.x), iy = rcp_core(rd.y), iz = rcp_core(rd.z);
+            const float x0 = (-0.5f - ro.x) * ix, x1 = (0.5f - ro.x) * ix;
+            const float y0 = (-0.5f - ro.y) * iy, y1 = (0.5f - ro.y) * iy;
+            const float z0 = (-0.5f - ro.z) * iz, z1 = (0.5f - ro.z) * iz;
+            const float nx = fminf(x0, x1), fx = fmaxf(x0, x1);
+            const float ny = fminf(y0, y1), fy = fmaxf(y0, y1);
+            const float nz = fminf(z0, z1), fz = fmaxf(z0, z1);
+            const float tmin = fmaxf(fmaxf(nx, ny), nz), tmax = fminf(fminf(fx, fy), fz);
+            if (tmax < tmin || tmax < 0) return false;
+            const bool entry = tmin > 0;
+            t = entry ? tmin : tmax;
+            // lowest axis attaining the extremum == the axis the sequential strict compares below end on
+            const bool isx = t == (entry ? nx : fx), isy = t == (entry ? ny : fy);
+            const float da = isx ? rd.x : (isy ? rd.y : rd.z);
+            face = (isx ? 0u : (isy ? 1u : 2u)) | (((da > 0) == entry) ? 4u : 0u);
+            return true;
+        }
     }
     float inv1, t0, t1, tn, tf;
     inv1 = rcp_rn(rd.x); t0 = (-0.5f - ro.x) * inv1; t1 = (0.5f - ro.x) * inv1;
