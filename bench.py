@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="iterations in flight per launch sequence (0 = library default)")
     ap.add_argument("--compaction", type=int, default=1, help="1 per-wave sharded (default), 2 workgroup scan, 0 off")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--direct-light", action="store_true", help="explicit light sampling (not the headline workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
@@ -72,13 +73,13 @@ def cpu_baseline(args, scene_path, rotat):
     sc_small = O.LoadedScene(scene_path, rotat)
     sc_small.set_resolution(args.width // 4, args.height // 4)
     _, live = O.render(sc_small.geoms, sc_small.n_objects, sc_small.mats, sc_small.n_materials, sc_small.camera,
-                       args.depth, iters=1, rr_start=args.rr_start, nthreads=cores)
+                       args.depth, iters=1, rr_start=args.rr_start, nthreads=cores, direct_light=1 if args.direct_light else 0)
     dt = time.perf_counter() - t0
     est_full = dt * 16.0
     spp = max(1, min(64, int(args.cpu_seconds / max(est_full, 1e-3))))
     t0 = time.perf_counter()
     _, live = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, args.depth, iters=spp,
-                       rr_start=args.rr_start, nthreads=cores)
+                       rr_start=args.rr_start, nthreads=cores, direct_light=1 if args.direct_light else 0)
     dt = time.perf_counter() - t0
     rb = int(live.sum())
     return {"value": rb / dt / 1e6, "unit": "Mray-bounces/s", "cores": cores, "kind": "port",
@@ -135,7 +136,8 @@ def main():
     r = pkg.Renderer(dev_index)
     r.set_options(depth=args.depth, rr_start=args.rr_start, workgroup=args.workgroup, geom_path=args.geom_path,
                   compaction=0 if args.no_compaction else args.compaction, batch=args.batch, use_graph=0 if args.no_graph else 1,
-                  row_begin=r0 if world > 1 else 0, row_end=r1 if world > 1 else 0)
+                  row_begin=r0 if world > 1 else 0, row_end=r1 if world > 1 else 0,
+                  direct_light=1 if args.direct_light else 0)
     r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
     r.set_camera(sc.camera)
     r.bind_image(fb.data_ptr())
@@ -229,10 +231,11 @@ def main():
                             f"{args.depth} bounces, diffuse+specular, rotat={args.rotat}, rr_start={args.rr_start}",
                 "scene": args.scene, "width": W, "height": Hfull, "depth": args.depth, "spp": args.steps,
                 "rotat_units": args.rotat, "primitives": sc.n_objects, "materials": sc.n_materials,
-                "compaction": 0 if args.no_compaction else args.compaction, "iteration_batch": args.batch or 8, "hip_graph": not args.no_graph,
+                "compaction": 0 if args.no_compaction else args.compaction, "iteration_batch": args.batch or 8, "hip_graph": not args.no_graph, "direct_light": bool(args.direct_light),
                 "parallelism": f"pixel-bands x{world}" + (", 1 RCCL gather" if world > 1 else ""),
             },
             "ray_bounces": int(rb_total),
+            "shadow_rays": int(st.shadow_rays),
             "live_in_per_bounce": live_in,
             "ms_per_frame_1spp": dt_max / args.steps * 1e3,
             "total_ms": dt_max * 1e3,

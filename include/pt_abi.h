@@ -93,7 +93,11 @@ typedef struct pt_options {
     int batch;            /* iterations rendered concurrently by one launch sequence, 1..8 (default 0 = library choice 8);
                              their samples are folded into the running mean in iteration order, so the image does not
                              depend on it */
-    int reserved[6];
+    int direct_light;     /* 1 = sample the lights explicitly at every diffuse vertex (one shadow ray; the reference's
+                             getRandomPointOnCube / getRandomPointOnSphere samplers, ref: src/intersections.h:133-182) and
+                             do not count a light hit by chance after such a vertex; 0 = pure path tracing (default).
+                             Needs compaction 1. */
+    int reserved[5];
 } pt_options;
 
 typedef struct pt_stats {
@@ -102,6 +106,7 @@ typedef struct pt_stats {
     unsigned long long live_in[PT_MAX_DEPTH];  /* the same, per bounce */
     double gpu_ms;                             /* HIP-event time of all pt_render calls on the render stream */
     unsigned long long bounce_launches;        /* per-bounce kernel launches inside those calls */
+    unsigned long long shadow_rays;            /* shadow rays cast by direct lighting (not part of ray_bounces) */
 } pt_stats;
 
 typedef struct pt_ctx pt_ctx;

@@ -226,8 +226,8 @@ o_vec3 o_getRadiuses(const o_staticGeom *geom)
     return v3(length3(sub3(xmax, origin)), length3(sub3(ymax, origin)), length3(sub3(zmax, origin)));
 }
 
-/* ref: src/intersections.h:133-175 */
-o_vec3 o_getRandomPointOnCube(const o_staticGeom *cube, float randomSeed)
+/* ref: src/intersections.h:133-175; also reports the object-space normal of the chosen face (direct lighting) */
+static o_vec3 cube_point(const o_staticGeom *cube, float randomSeed, o_vec3 *face_normal_obj)
 {
     unsigned rng; o_minstd_seed(&rng, o_hash((unsigned)randomSeed));
 
@@ -239,27 +239,56 @@ o_vec3 o_getRandomPointOnCube(const o_staticGeom *cube, float randomSeed)
 
     float russianRoulette = o_uniform_real(&rng, 0, 1);
 
-    o_vec3 point;
+    o_vec3 point, nobj;
     if (russianRoulette < (side1 / totalarea)) {
         float a = o_uniform_real(&rng, -0.5f, 0.5f), b = o_uniform_real(&rng, -0.5f, 0.5f);
-        point = v3(a, b, .5f);
+        point = v3(a, b, .5f); nobj = v3(0, 0, 1);
     } else if (russianRoulette < ((side1 * 2) / totalarea)) {
         float a = o_uniform_real(&rng, -0.5f, 0.5f), b = o_uniform_real(&rng, -0.5f, 0.5f);
-        point = v3(a, b, -.5f);
+        point = v3(a, b, -.5f); nobj = v3(0, 0, -1);
     } else if (russianRoulette < (((side1 * 2) + (side2)) / totalarea)) {
         float a = o_uniform_real(&rng, -0.5f, 0.5f), b = o_uniform_real(&rng, -0.5f, 0.5f);
-        point = v3(.5f, a, b);
+        point = v3(.5f, a, b); nobj = v3(1, 0, 0);
     } else if (russianRoulette < (((side1 * 2) + (side2 * 2)) / totalarea)) {
         float a = o_uniform_real(&rng, -0.5f, 0.5f), b = o_uniform_real(&rng, -0.5f, 0.5f);
-        point = v3(-.5f, a, b);
+        point = v3(-.5f, a, b); nobj = v3(-1, 0, 0);
     } else if (russianRoulette < (((side1 * 2) + (side2 * 2) + (side3)) / totalarea)) {
         float a = o_uniform_real(&rng, -0.5f, 0.5f), b = o_uniform_real(&rng, -0.5f, 0.5f);
-        point = v3(a, .5f, b);
+        point = v3(a, .5f, b); nobj = v3(0, 1, 0);
     } else {
         float a = o_uniform_real(&rng, -0.5f, 0.5f), b = o_uniform_real(&rng, -0.5f, 0.5f);
-        point = v3(a, -.5f, b);
+        point = v3(a, -.5f, b); nobj = v3(0, -1, 0);
     }
+    if (face_normal_obj) *face_normal_obj = nobj;
     return o_multiplyMV(cube->transform, v4(point, 1.0f));
+}
+o_vec3 o_getRandomPointOnCube(const o_staticGeom *cube, float randomSeed) { return cube_point(cube, randomSeed, NULL); }
+
+/* spec (DESIGN.md "Direct lighting"): surface area of a light, from getRadiuses' half-extents.  Cube: the
+ * total area getRandomPointOnCube weights its faces with.  Sphere (r = .5 in object space): 4pi(ab+ac+bc)/3,
+ * exact for uniform scale. */
+float o_lightArea(const o_staticGeom *g)
+{
+    o_vec3 r = o_getRadiuses(g);
+    if (g->type == O_CUBE) {
+        float side1 = r.x * r.y * 4.0f, side2 = r.z * r.y * 4.0f, side3 = r.x * r.z * 4.0f;
+        return 2.0f * (side1 + side2 + side3);
+    }
+    return 4.18879020478639098f * ((r.x * r.y + r.x * r.z) + r.y * r.z);
+}
+
+/* spec: a point on light `g` and the geometric normal there, from one float seed (the reference's sampler
+ * interface, src/intersections.h:133,179) */
+void o_sampleLight(const o_staticGeom *g, float randomSeed, o_vec3 *point, o_vec3 *normal)
+{
+    if (g->type == O_CUBE) {
+        o_vec3 nobj;
+        *point = cube_point(g, randomSeed, &nobj);
+        *normal = normalize3(o_multiplyMV(g->transform, v4(nobj, 0.0f)));         /* as the box test's normal */
+    } else {
+        *point = o_getRandomPointOnSphere(g, randomSeed);
+        *normal = normalize3(sub3(*point, o_multiplyMV(g->transform, v4(v3(0, 0, 0), 1.0f))));   /* as the sphere test's */
+    }
 }
 
 /* spec (ref stub: src/intersections.h:177-182): uniform point on the object-space sphere r=.5 */
@@ -486,7 +515,7 @@ void o_sendImageToPBO(unsigned char *pbo, int npixels, const float *image)
 void o_clearImage(float *image, int npixels) { memset(image, 0, (size_t)npixels * 3 * sizeof(float)); }
 
 /* spec: nearest hit over the whole primitive list; smallest t > 0, ties -> lowest index */
-static int nearest_hit(const o_staticGeom *geoms, int nG, o_ray r, o_vec3 *p, o_vec3 *n)
+static int nearest_hit(const o_staticGeom *geoms, int nG, o_ray r, o_vec3 *p, o_vec3 *n, float *t_out)
 {
     int best = -1; float best_t = 0;
     for (int i = 0; i < nG; i++) {
@@ -496,36 +525,92 @@ static int nearest_hit(const o_staticGeom *geoms, int nG, o_ray r, o_vec3 *p, o_
         else t = -1;                                      /* MESH: parsed, never loaded (ref: src/scene.cpp:57-66) */
         if (t > 0 && (best < 0 || t < best_t)) { best = i; best_t = t; *p = ip; *n = in; }
     }
+    if (t_out) *t_out = best_t;
     return best;
 }
 
 /* spec: one path.  Returns the radiance sample L_i of this iteration. */
+typedef struct { int n; int prim[O_MAX_LIGHTS]; float area[O_MAX_LIGHTS]; } light_table;
+
+/* spec (DESIGN.md "Direct lighting"): emissive primitives in list order, at most O_MAX_LIGHTS */
+static void collect_lights(const o_staticGeom *geoms, int nG, const o_material *mats, light_table *lt)
+{
+    lt->n = 0;
+    for (int i = 0; i < nG && lt->n < O_MAX_LIGHTS; i++) {
+        if (geoms[i].type == O_MESH) continue;
+        if (mats[geoms[i].materialid].emittance > 0.0f) {
+            lt->prim[lt->n] = i;
+            lt->area[lt->n] = o_lightArea(&geoms[i]);
+            lt->n++;
+        }
+    }
+}
+
 static o_vec3 trace_path(const o_staticGeom *geoms, int nG, const o_material *mats, const cam_basis *cb,
-                         const o_options *opt, int W, int x, int y, unsigned iteration, int *bounces,
-                         unsigned long long *live_in)
+                         const o_options *opt, const light_table *lt, int W, int x, int y, unsigned iteration,
+                         int *bounces, unsigned long long *live_in, unsigned long long *shadow_rays)
 {
     unsigned pixel = (unsigned)x + (unsigned)y * (unsigned)W;
     unsigned rng; o_minstd_seed(&rng, o_stream_seed(pixel, iteration, 0u, opt->seed));
     float jx = o_u01(&rng), jy = o_u01(&rng);
     o_ray r = camera_ray(cb, x, y, jx, jy);
     o_vec3 T = v3(1, 1, 1), L = v3(0, 0, 0);
+    const int nee = opt->direct_light && lt && lt->n > 0;          /* explicit light sampling at diffuse vertices */
+    int suppress = 0;     /* the previous vertex sampled the lights explicitly: hitting one by chance adds nothing */
 
     for (int b = 0; b < opt->depth; b++) {
         if (bounces) (*bounces)++;
         if (live_in) live_in[b]++;
         o_vec3 p, n;
-        int hit = nearest_hit(geoms, nG, r, &p, &n);
+        int hit = nearest_hit(geoms, nG, r, &p, &n, NULL);
         if (hit < 0) break;                                        /* background is black */
         const o_material *m = &mats[geoms[hit].materialid];
         if (m->emittance > 0.0f) {                                 /* light: emit and stop */
-            L = scale3(m->emittance, mul3(T, m->color));
+            if (!suppress) L = add3(L, scale3(m->emittance, mul3(T, m->color)));
             break;
         }
-        if (b == opt->depth - 1) break;                            /* depth exhausted: no contribution */
+        if (b == opt->depth - 1 && !nee) break;                    /* depth exhausted: no contribution */
 
         o_minstd_seed(&rng, o_stream_seed(pixel, iteration, (unsigned)b + 1u, opt->seed));
         float u_select = o_u01(&rng), xi1 = o_u01(&rng), xi2 = o_u01(&rng), u_rr = o_u01(&rng);
+
+        const int diffuse = !(m->hasRefractive > 0.0f) && !(m->hasReflective > 0.0f);
+        if (nee && diffuse) {
+            /* spec (ref samplers src/intersections.h:133-182): one light by u_light, one point on
+             * it by the reference's float-seeded sampler, one shadow ray; estimator
+             * T*c/pi * Le * cos_x cos_y / d^2 * (area * number of lights) */
+            float u_light = o_u01(&rng), u_seed = o_u01(&rng);
+            int j = (int)(u_light * (float)lt->n);
+            if (j > lt->n - 1) j = lt->n - 1;
+            const o_staticGeom *lg = &geoms[lt->prim[j]];
+            o_vec3 yl, nl;
+            o_sampleLight(lg, u_seed * 16777216.0f, &yl, &nl);
+            o_vec3 nf = (dot3(n, r.direction) > 0.0f) ? neg3(n) : n;
+            o_ray sr;
+            sr.origin = add3(p, scale3(O_RAY_BIAS_AMOUNT, nf));
+            o_vec3 wi = sub3(yl, sr.origin);
+            float d2 = dot3(wi, wi);
+            float dist = sqrtf(d2);
+            sr.direction = normalize3(wi);
+            float cx = dot3(nf, sr.direction), cy = -dot3(nl, sr.direction);
+            if (cx > 0.0f && cy > 0.0f) {
+                if (shadow_rays) (*shadow_rays)++;
+                o_vec3 hp, hn; float ht;
+                int hs = nearest_hit(geoms, nG, sr, &hp, &hn, &ht);
+                float tol = 1e-3f * ((dist > 1.0f) ? dist : 1.0f);
+                if (hs == lt->prim[j] && fabsf(ht - dist) <= tol) {
+                    const o_material *lm = &mats[lg->materialid];
+                    float G = (cx * cy) / d2;
+                    float wgt = (G * (lt->area[j] * (float)lt->n)) * 0.318309886f;
+                    o_vec3 c = mul3(mul3(T, m->color), scale3(lm->emittance, lm->color));
+                    L = add3(L, scale3(wgt, c));
+                }
+            }
+        }
+        if (b == opt->depth - 1) break;                            /* depth exhausted */
+
         o_calculateBSDF(&r, p, n, &T, m, u_select, xi1, xi2, opt->trig_mode);
+        suppress = nee && diffuse;
 
         if (opt->rr_start >= 0 && b >= opt->rr_start) {            /* Russian roulette */
             float q = T.x;
@@ -553,14 +638,18 @@ o_vec3 o_trace_path(const o_staticGeom *geoms, int nG, const o_material *mats, i
 {
     if (validate(geoms, nG, nM, cam, opt) != 0) return v3(-1, -1, -1);
     cam_basis cb = camera_basis(cam->resolution, cam->position, cam->view, cam->up, cam->fov);
+    light_table lt;
+    collect_lights(geoms, nG, mats, &lt);
     if (bounces_out) *bounces_out = 0;
-    return trace_path(geoms, nG, mats, &cb, opt, (int)cam->resolution.x, x, y, iteration, bounces_out, NULL);
+    return trace_path(geoms, nG, mats, &cb, opt, &lt, (int)cam->resolution.x, x, y, iteration, bounces_out, NULL, NULL);
 }
 
 typedef struct {
     const o_staticGeom *geoms; int nG; const o_material *mats; const cam_basis *cb; const o_options *opt;
     float *image; int W, H; int iter_first, iter_count; int row0, row1;
     unsigned long long *live_in;   /* private per thread, depth entries */
+    unsigned long long shadow_rays;
+    const light_table *lt;
 } job;
 
 static void *render_rows(void *arg)
@@ -569,8 +658,8 @@ static void *render_rows(void *arg)
     for (int it = j->iter_first; it < j->iter_first + j->iter_count; it++) {
         for (int y = j->row0; y < j->row1; y++) {
             for (int x = 0; x < j->W; x++) {
-                o_vec3 L = trace_path(j->geoms, j->nG, j->mats, j->cb, j->opt, j->W, x, y, (unsigned)it,
-                                      NULL, j->live_in);
+                o_vec3 L = trace_path(j->geoms, j->nG, j->mats, j->cb, j->opt, j->lt, j->W, x, y, (unsigned)it,
+                                      NULL, j->live_in, &j->shadow_rays);
                 /* spec: running mean, stateless given (image, iteration) */
                 float *px = &j->image[3 * ((size_t)x + (size_t)y * (size_t)j->W)];
                 float fi = (float)it, fim1 = (float)(it - 1);
@@ -587,11 +676,20 @@ int o_render(const o_staticGeom *geoms, int nG, const o_material *mats, int nM, 
              const o_options *opt, float *image, int iter_first, int iter_count,
              unsigned long long *live_in, int nthreads)
 {
+    return o_render_counted(geoms, nG, mats, nM, cam, opt, image, iter_first, iter_count, live_in, NULL, nthreads);
+}
+
+int o_render_counted(const o_staticGeom *geoms, int nG, const o_material *mats, int nM, const o_cameraData *cam,
+                     const o_options *opt, float *image, int iter_first, int iter_count,
+                     unsigned long long *live_in, unsigned long long *shadow_rays, int nthreads)
+{
     int rc = validate(geoms, nG, nM, cam, opt);
     if (rc != 0) return rc;
     if (!image || iter_first < 1 || iter_count < 0) return -4;
     int W = (int)cam->resolution.x, H = (int)cam->resolution.y;
     cam_basis cb = camera_basis(cam->resolution, cam->position, cam->view, cam->up, cam->fov);
+    light_table lt;
+    collect_lights(geoms, nG, mats, &lt);
     if (nthreads < 1) nthreads = 1;
     if (nthreads > H) nthreads = H;
     if (nthreads > 256) nthreads = 256;
@@ -606,6 +704,8 @@ int o_render(const o_staticGeom *geoms, int nG, const o_material *mats, int nM, 
         j->W = W; j->H = H; j->iter_first = iter_first; j->iter_count = iter_count;
         j->row0 = (int)((long long)H * t / nthreads); j->row1 = (int)((long long)H * (t + 1) / nthreads);
         j->live_in = counts + (size_t)t * (size_t)opt->depth;
+        j->shadow_rays = 0;
+        j->lt = &lt;
     }
     if (nthreads == 1) render_rows(&jobs[0]);
     else {
@@ -618,6 +718,8 @@ int o_render(const o_staticGeom *geoms, int nG, const o_material *mats, int nM, 
             for (int t = 0; t < nthreads; t++) s += counts[(size_t)t * (size_t)opt->depth + (size_t)b];
             live_in[b] += s;
         }
+    if (shadow_rays)
+        for (int t = 0; t < nthreads; t++) *shadow_rays += jobs[t].shadow_rays;
     free(counts);
     return 0;
 }

@@ -64,13 +64,13 @@ class CameraData(C.Structure):
 class Options(C.Structure):
     _fields_ = [("depth", C.c_int), ("rr_start", C.c_int), ("seed", C.c_uint), ("compaction", C.c_int),
                 ("workgroup", C.c_int), ("geom_path", C.c_int), ("row_begin", C.c_int), ("row_end", C.c_int),
-                ("use_graph", C.c_int), ("batch", C.c_int), ("reserved", C.c_int * 6)]
+                ("use_graph", C.c_int), ("batch", C.c_int), ("direct_light", C.c_int), ("reserved", C.c_int * 5)]
 
 
 class Stats(C.Structure):
     _fields_ = [("iterations", C.c_ulonglong), ("ray_bounces", C.c_ulonglong),
                 ("live_in", C.c_ulonglong * PT_MAX_DEPTH), ("gpu_ms", C.c_double),
-                ("bounce_launches", C.c_ulonglong)]
+                ("bounce_launches", C.c_ulonglong), ("shadow_rays", C.c_ulonglong)]
 
 
 class PtError(RuntimeError):

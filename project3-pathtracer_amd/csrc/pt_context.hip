@@ -68,6 +68,7 @@ struct pt_ctx {
     ptd::Prim *d_prims = nullptr;
     float *d_mats = nullptr;
     float *d_ro_eye = nullptr;
+    int *d_lights = nullptr;    // direct lighting: indices of the emissive primitives
     ptd::BvhNode *d_bvh = nullptr;
     float *d_image_own = nullptr;
     float *d_image_bound = nullptr;
@@ -255,6 +256,40 @@ int configure(pt_ctx *c)
             rad = rad * 1.02 + 1e-3;
             p.bound_r2 = (float)(rad * rad);
         }
+        // direct lighting: emissive primitives in list order (at most 16), their surface area from getRadiuses'
+        // half-extents (ref: src/intersections.h:120-129) in fp32 with the sampler's own operation order
+        std::vector<int> lights;
+        for (size_t i = 0; i < c->geoms.size() && lights.size() < 16; ++i) {
+            const pt_static_geom &g = c->geoms[i];
+            if (g.type == PT_MESH || !(c->mats[(size_t)g.materialid].emittance > 0.0f)) continue;
+            const pt_mat4 &m = g.transform;
+            auto mv = [&](float x, float y, float z, float out[3]) {
+                out[0] = (m.x.x * x) + (m.x.y * y) + (m.x.z * z) + (m.x.w * 1.0f);
+                out[1] = (m.y.x * x) + (m.y.y * y) + (m.y.z * z) + (m.y.w * 1.0f);
+                out[2] = (m.z.x * x) + (m.z.y * y) + (m.z.z * z) + (m.z.w * 1.0f);
+            };
+            float org[3], ax[3][3], r[3];
+            mv(0, 0, 0, org); mv(.5f, 0, 0, ax[0]); mv(0, .5f, 0, ax[1]); mv(0, 0, .5f, ax[2]);
+            for (int a = 0; a < 3; ++a) {
+                const float dx = ax[a][0] - org[0], dy = ax[a][1] - org[1], dz = ax[a][2] - org[2];
+                r[a] = sqrtf(dx * dx + dy * dy + dz * dz);
+            }
+            float area;
+            if (g.type == PT_CUBE) {
+                const float side1 = r[0] * r[1] * 4.0f, side2 = r[2] * r[1] * 4.0f, side3 = r[0] * r[2] * 4.0f;
+                area = 2.0f * (side1 + side2 + side3);
+            } else {
+                area = 4.18879020478639098f * ((r[0] * r[1] + r[0] * r[2]) + r[1] * r[2]);
+            }
+            prims[i].area = area;
+            lights.push_back((int)i);
+        }
+        k.nlights = o.direct_light ? (int)lights.size() : 0;
+        if (c->d_lights) { (void)hipFree(c->d_lights); c->d_lights = nullptr; }
+        HIP_TRY(hipMalloc((void **)&c->d_lights, (lights.size() ? lights.size() : 1) * sizeof(int)));
+        if (!lights.empty()) HIP_TRY(hipMemcpy(c->d_lights, lights.data(), lights.size() * sizeof(int), hipMemcpyHostToDevice));
+        k.lights = c->d_lights;
+
         if (c->d_prims) { (void)hipFree(c->d_prims); c->d_prims = nullptr; }
         HIP_TRY(hipMalloc((void **)&c->d_prims, prims.size() * sizeof(ptd::Prim)));
         HIP_TRY(hipMemcpy(c->d_prims, prims.data(), prims.size() * sizeof(ptd::Prim), hipMemcpyHostToDevice));
@@ -349,6 +384,7 @@ int configure(pt_ctx *c)
     // library choice: the hit queue pays when most primitives are hit by some lane of every wave (small scenes)
     cfg.geom = o.geom_path == 0 ? (k.nG <= 32 ? 2 : 3) : o.geom_path - 1;
     cfg.compact = o.compaction;
+    cfg.nee = k.nlights > 0 ? 1 : 0;             // no lights: nothing to sample, the plain kernels are exact
     k.cull = (k.nG > 32 && !getenv("PT_NO_CULL")) ? 1 : 0;
     k.nshard = (cfg.compact == 1) ? pt::NSHARD : 1;
     const size_t lds = pt::bounce_lds_bytes(k, cfg);
@@ -500,6 +536,7 @@ void pt_destroy(pt_ctx *c)
     if (c->d_prims) (void)hipFree(c->d_prims);
     if (c->d_mats) (void)hipFree(c->d_mats);
     if (c->d_ro_eye) (void)hipFree(c->d_ro_eye);
+    if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_bvh) (void)hipFree(c->d_bvh);
     if (c->d_image_own) (void)hipFree(c->d_image_own);
     if (c->d_pool) (void)hipFree(c->d_pool);
@@ -520,6 +557,8 @@ int pt_set_options(pt_ctx *c, const pt_options *o)
     if (o->row_begin < 0 || o->row_end < o->row_begin) return fail(PT_ERR_INVALID, "tile rows [%d,%d)", o->row_begin, o->row_end);
     if (o->batch < 0 || o->batch > pt::PT_MAX_BATCH) return fail(PT_ERR_INVALID, "batch %d not in 0..%d", o->batch, pt::PT_MAX_BATCH);
     if (o->compaction < 0 || o->compaction > 2) return fail(PT_ERR_INVALID, "compaction %d not 0, 1 or 2", o->compaction);
+    if (o->direct_light < 0 || o->direct_light > 1) return fail(PT_ERR_INVALID, "direct_light %d not 0 or 1", o->direct_light);
+    if (o->direct_light && o->compaction != 1) return fail(PT_ERR_INVALID, "direct_light needs compaction 1 (got %d)", o->compaction);
     c->opt = *o;
     c->dirty = true;
     return PT_OK;
@@ -794,6 +833,7 @@ int pt_get_stats(pt_ctx *c, pt_stats *out)
         fprintf(stderr, "[ptamd] bounce-1 workgroup 0: %llu shader clocks in %llu x 10 ns -> %.0f MHz\n", h.clk[0], h.clk[1],
                 (double)h.clk[0] / (double)h.clk[1] * 100.0);
     out->bounce_launches = c->bounce_launches;
+    out->shadow_rays = h.shadow_rays;
     return PT_OK;
 }
 

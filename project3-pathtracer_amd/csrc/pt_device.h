@@ -96,7 +96,8 @@ __device__ __forceinline__ f3 normalize(f3 v)
 struct Prim {
     uint32_t type;       // 0 sphere, 1 cube, 2 mesh (never hit)
     uint32_t material;
-    uint32_t pad0, pad1;
+    float area;          // surface area when the primitive is a light (direct lighting), else 0
+    uint32_t pad1;
     float inv[12];       // inverseTransform rows x,y,z (x y z w each)
     float fwd[12];       // transform rows x,y,z
     float cx, cy, cz;    // transform * (0,0,0,1), evaluated on the host with multiplyMV's operation order
@@ -376,8 +377,9 @@ __device__ __forceinline__ f3 getRadiuses(const float *fwd)
     return mk(length(xmax - origin), length(ymax - origin), length(zmax - origin));
 }
 
-// getRandomPointOnCube (ref: src/intersections.h:133-175): area-weighted face choice, then a point on the face
-__device__ __forceinline__ f3 getRandomPointOnCube(const float *fwd, float randomSeed)
+// getRandomPointOnCube (ref: src/intersections.h:133-175): area-weighted face choice, then a point on the face;
+// nobj = object-space normal of that face
+__device__ __forceinline__ f3 cubePoint(const float *fwd, float randomSeed, f3 &nobj)
 {
     uint32_t rng = minstd_seed(wang_hash((uint32_t)randomSeed));
     const f3 radii = getRadiuses(fwd);
@@ -386,13 +388,18 @@ __device__ __forceinline__ f3 getRandomPointOnCube(const float *fwd, float rando
     const float russianRoulette = uniform_real(rng, 0, 1);
     const float a = uniform_real(rng, -0.5f, 0.5f), b = uniform_real(rng, -0.5f, 0.5f);
     f3 point;
-    if (russianRoulette < (side1 / totalarea)) point = mk(a, b, .5f);
-    else if (russianRoulette < ((side1 * 2) / totalarea)) point = mk(a, b, -.5f);
-    else if (russianRoulette < (((side1 * 2) + (side2)) / totalarea)) point = mk(.5f, a, b);
-    else if (russianRoulette < (((side1 * 2) + (side2 * 2)) / totalarea)) point = mk(-.5f, a, b);
-    else if (russianRoulette < (((side1 * 2) + (side2 * 2) + (side3)) / totalarea)) point = mk(a, .5f, b);
-    else point = mk(a, -.5f, b);
+    if (russianRoulette < (side1 / totalarea)) { point = mk(a, b, .5f); nobj = mk(0, 0, 1); }
+    else if (russianRoulette < ((side1 * 2) / totalarea)) { point = mk(a, b, -.5f); nobj = mk(0, 0, -1); }
+    else if (russianRoulette < (((side1 * 2) + (side2)) / totalarea)) { point = mk(.5f, a, b); nobj = mk(1, 0, 0); }
+    else if (russianRoulette < (((side1 * 2) + (side2 * 2)) / totalarea)) { point = mk(-.5f, a, b); nobj = mk(-1, 0, 0); }
+    else if (russianRoulette < (((side1 * 2) + (side2 * 2) + (side3)) / totalarea)) { point = mk(a, .5f, b); nobj = mk(0, 1, 0); }
+    else { point = mk(a, -.5f, b); nobj = mk(0, -1, 0); }
     return mulMV(fwd, point, 1.0f);
+}
+__device__ __forceinline__ f3 getRandomPointOnCube(const float *fwd, float randomSeed)
+{
+    f3 nobj;
+    return cubePoint(fwd, randomSeed, nobj);
 }
 
 // getRandomDirectionInSphere (stub ref: src/interactions.h:89-95): uniform direction, deterministic trig
@@ -414,6 +421,20 @@ __device__ __forceinline__ f3 getRandomPointOnSphere(const float *fwd, float ran
     const float xi1 = uniform_real(rng, 0, 1), xi2 = uniform_real(rng, 0, 1);
     const f3 d = getRandomDirectionInSphere(xi1, xi2);
     return mulMV(fwd, 0.5f * d, 1.0f);
+}
+
+// Direct lighting: a point on a light and the geometric normal there, from one float seed (the reference's sampler
+// interface).  Normals as the intersection tests define them (boxNormal / sphereNormal).
+__device__ __forceinline__ void sampleLight(uint32_t type, const float *fwd, f3 center, float randomSeed, f3 &point, f3 &normal)
+{
+    if (type == 1u) {
+        f3 nobj;
+        point = cubePoint(fwd, randomSeed, nobj);
+        normal = normalize(mulMV(fwd, nobj, 0.0f));
+    } else {
+        point = getRandomPointOnSphere(fwd, randomSeed);
+        normal = normalize(point - center);
+    }
 }
 
 }  // namespace ptd

@@ -36,6 +36,7 @@ struct IterState {
     unsigned long long live_in[PT_MAX_DEPTH];    // summed over segments and iterations (stats)
     unsigned long long iterations;
     unsigned long long clk[4];                   // diagnostics: shader-clock / real-time ticks spent by workgroup 0 of the last bounce-1 launch
+    unsigned long long shadow_rays;              // shadow rays cast (direct lighting), stats
 };
 
 struct KParams {
@@ -65,6 +66,8 @@ struct KParams {
     uint32_t segcap;       // slots per pool segment
     IterState *st;
     RayPool pool[2];
+    int nlights;           // direct lighting: emissive primitives (0 = feature off), indices in `lights`
+    const int *lights;
 };
 
 struct LaunchCfg {
@@ -72,6 +75,7 @@ struct LaunchCfg {
     int grid;        // workgroups per bounce launch
     int geom;        // 0 scalar direct, 1 LDS direct, 2 hit queue, 3 per-lane hierarchy walk (pt_kernels.hip)
     int compact;     // 0 off, 1 per-wave sharded reservation, 2 workgroup scan + single counter
+    int nee;         // 1 = explicit light sampling at diffuse vertices (compact must be 1)
 };
 
 // kernels (pt_kernels.hip)

@@ -46,6 +46,8 @@ __device__ __forceinline__ Prim load_prim_scalar(const Prim *prims, int g)
 struct Hit {
     f3 p, n;
     uint32_t material;
+    uint32_t prim;      // index of the primitive hit (used by shadow rays)
+    float t;            // world-space distance to the hit
     bool any;
 };
 
@@ -92,6 +94,7 @@ __device__ __forceinline__ Hit nearestHitDirect(const KParams &p, const Prim *s_
     Hit h;
     h.any = false;
     h.material = 0;
+    h.prim = 0;
     h.p = mk(0, 0, 0);
     h.n = mk(0, 0, 0);
     float best_t = 0.0f;
@@ -120,8 +123,10 @@ __device__ __forceinline__ Hit nearestHitDirect(const KParams &p, const Prim *s_
             h.p = ip;
             h.n = in;
             h.material = mat;
+            h.prim = (uint32_t)g;
         }
     }
+    h.t = best_t;
     return h;
 }
 
@@ -190,6 +195,8 @@ __device__ __forceinline__ Hit nearestHitBvh(const KParams &p, const Prim *s_pri
             h.material = P.material;
         }
     }
+    h.prim = best_g;
+    h.t = best_t;
     return h;
 }
 
@@ -276,6 +283,8 @@ __device__ __forceinline__ Hit nearestHitQueued(const KParams &p, const Prim *s_
     Hit h;
     h.any = false;
     h.material = 0;
+    h.prim = 0;
+    h.t = 0.0f;
     h.p = mk(0, 0, 0);
     h.n = mk(0, 0, 0);
     const unsigned long long k = q.key[lane];
@@ -286,6 +295,8 @@ __device__ __forceinline__ Hit nearestHitQueued(const KParams &p, const Prim *s_
         const uint32_t face = meta >> 28;
         const Prim &P = s_prims[prim];                       // per-lane gather from the LDS copy
         h.any = true;
+        h.prim = prim;
+        h.t = __uint_as_float((uint32_t)(k >> 32));
         h.p = mk(b.x, b.y, b.z);
         h.material = P.material;
         if (P.type == 0u) {
@@ -301,9 +312,35 @@ __device__ __forceinline__ Hit nearestHitQueued(const KParams &p, const Prim *s_
     return h;
 }
 
+// nearest hit of (o, d) for the lanes with want == true, by the GEOM path.  Every lane of the wave must make the call
+// (the hit queue uses all 64 lanes as workers whatever their own ray).
+template <int GEOM, bool FIRST>
+__device__ __forceinline__ Hit nearestHit(const KParams &p, const Prim *s_prims, const float4 *s_nodes, const WaveQueue &wq,
+                                          f3 o, f3 d, bool want, uint32_t lane)
+{
+    if (GEOM == GEOM_QUEUE) return nearestHitQueued<FIRST>(p, s_prims, wq, o, d, want, lane);
+    Hit h;
+    h.any = false;
+    h.material = 0;
+    h.prim = 0;
+    h.t = 0.0f;
+    h.p = mk(0, 0, 0);
+    h.n = mk(0, 0, 0);
+    if (GEOM == GEOM_BVH) {
+        if (want) h = nearestHitBvh<FIRST>(p, p.prims, s_nodes, o, d);
+    } else {
+        if (want) h = nearestHitDirect<(GEOM == GEOM_LDS ? GEOM_LDS : GEOM_SCALAR), FIRST>(p, s_prims, o, d);
+    }
+    return h;
+}
+
 // COMPACT: 0 = rays keep their slot (validation / ablation), 1 = per-wave reservation on sharded counters
 // (no workgroup barrier), 2 = LDS scan over the workgroup's waves + one atomic per workgroup.
-template <int WG, bool FIRST, int GEOM, int COMPACT>
+// NEE: explicit light sampling at diffuse vertices (pt_options.direct_light).  A ray then carries in bit 31 of its
+// pixel word whether its previous vertex sampled the lights (a light hit by chance adds nothing), the radiance planes
+// accumulate along the path (every path initialises its entry at bounce 0), and each chunk makes a second pass through
+// the nearest-hit machinery for the shadow rays.
+template <int WG, bool FIRST, int GEOM, int COMPACT, bool NEE = false>
 __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce)
 {
     constexpr int NW = WG / 64;
@@ -383,6 +420,7 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
     const uint32_t out_base = myshard * p.segcap;
 
     uint32_t live_count = 0;      // COMPACT 0: rays this wave found alive on entry
+    uint32_t shadow_count = 0;    // NEE: shadow rays this wave traced
     int round = 0;
     for (uint32_t R = blockIdx.x; R * NW < total_chunks; R += gridDim.x, ++round) {     // workgroup-uniform trip count
         const uint32_t chunk = R * NW + wave;
@@ -441,27 +479,25 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
         if (COMPACT == 0) live_count += (uint32_t)__popcll(__ballot(valid));
 
         bool alive = false;
-        Hit h;
-        if (GEOM == GEOM_QUEUE) {
-            h = nearestHitQueued<FIRST>(p, s_prims, wq, o, d, valid, (uint32_t)lane);   // whole wave, see above
-        } else if (GEOM == GEOM_BVH) {
-            h.any = false;
-            if (valid) h = nearestHitBvh<FIRST>(p, p.prims, s_nodes, o, d);
-        } else {
-            h.any = false;
-            if (valid) h = nearestHitDirect<(GEOM == GEOM_LDS ? GEOM_LDS : GEOM_SCALAR), FIRST>(p, s_prims, o, d);
-        }
+        const Hit h = nearestHit<GEOM, FIRST>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane);
+        f3 L = mk(0, 0, 0);               // radiance this vertex adds to the path's sample
+        // direct lighting: the shadow ray this lane wants traced and what it is worth if the light is visible
+        bool want_shadow = false;
+        f3 so = mk(0, 0, 0), sd = mk(0, 0, 0), Ld = mk(0, 0, 0);
+        uint32_t lprim = 0;
+        float ldist = 0.0f;
         if (valid) {
-            f3 L = mk(0, 0, 0);
             if (h.any) {
                 const uint32_t m = h.material;
                 const float emit = s_mats[M_EMIT * p.nM + m];
                 if (emit > 0.0f) {
-                    const f3 col = mk(s_mats[M_CR * p.nM + m], s_mats[M_CG * p.nM + m], s_mats[M_CB * p.nM + m]);
-                    L = emit * (T * col);
-                } else if (!last) {
+                    if (!NEE || (pix >> 31) == 0u) {
+                        const f3 col = mk(s_mats[M_CR * p.nM + m], s_mats[M_CG * p.nM + m], s_mats[M_CB * p.nM + m]);
+                        L = emit * (T * col);
+                    }
+                } else if (!last || NEE) {
                     // calculateBSDF: pick the lobe, build the next ray
-                    const uint32_t slot = pix >> SLOT_SHIFT;
+                    const uint32_t slot = NEE ? ((pix >> SLOT_SHIFT) & (uint32_t)(MAXSLOT - 1)) : (pix >> SLOT_SHIFT);
                     uint32_t kb = key_bounce[0];
 #pragma unroll
                     for (uint32_t k = 1; k < (uint32_t)MAXSLOT; ++k) kb = (slot == k) ? key_bounce[k] : kb;
@@ -480,6 +516,41 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
                     const f3 nf = backside ? -h.n : h.n;
                     const float refr = s_mats[M_REFR * p.nM + m];
                     const float refl = s_mats[M_REFL * p.nM + m];
+                    const bool diffuse = !(refr > 0.0f) && !(refl > 0.0f);
+                    if (NEE && diffuse) {
+                        // one light, one point on it (the reference's float-seeded samplers), one shadow ray;
+                        // estimator T*c/pi * Le * cos_x cos_y / d^2 * (area * number of lights)
+                        s = minstd_next(s);
+                        const float u_light = u01_of(s);
+                        s = minstd_next(s);
+                        const float u_seed = u01_of(s);
+                        int j = (int)(u_light * (float)p.nlights);
+                        if (j > p.nlights - 1) j = p.nlights - 1;
+                        lprim = (uint32_t)p.lights[j];
+                        const Prim *LP = PRIMS_IN_LDS ? &s_prims[lprim] : &p.prims[lprim];
+                        const uint4 hd = *reinterpret_cast<const uint4 *>(LP);           // type, material, area, pad
+                        const float4 *fw = reinterpret_cast<const float4 *>(LP->fwd);
+                        const float4 f0 = fw[0], f1 = fw[1], f2 = fw[2], cc = fw[3];   // fwd rows, (cx, cy, cz, bound)
+                        const float fwd[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
+                        f3 yl, nl;
+                        sampleLight(hd.x, fwd, mk(cc.x, cc.y, cc.z), u_seed * 16777216.0f, yl, nl);
+                        so = h.p + 0.0002f * nf;
+                        const f3 wi = yl - so;
+                        const float d2 = dot(wi, wi);
+                        ldist = sqrt_rn(d2);
+                        sd = normalize(wi);
+                        const float cx = dot(nf, sd), cy = -dot(nl, sd);
+                        if (cx > 0.0f && cy > 0.0f) {
+                            want_shadow = true;
+                            const float G = (cx * cy) / d2;
+                            const float wgt = (G * (__uint_as_float(hd.z) * (float)p.nlights)) * 0.318309886f;
+                            const uint32_t lm = hd.y;
+                            const f3 col = mk(s_mats[M_CR * p.nM + m], s_mats[M_CG * p.nM + m], s_mats[M_CB * p.nM + m]);
+                            const f3 lcol = mk(s_mats[M_CR * p.nM + lm], s_mats[M_CG * p.nM + lm], s_mats[M_CB * p.nM + lm]);
+                            Ld = wgt * ((T * col) * (s_mats[M_EMIT * p.nM + lm] * lcol));
+                        }
+                    }
+                    if (!last) {
                     f3 nd;
                     f3 bias_n = nf;
                     if (refr > 0.0f) {
@@ -511,16 +582,41 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
                         if (u_rr >= q) alive = false;
                         else T = mk(T.x / q, T.y / q, T.z / q);
                     }
+                    if (NEE) pix = (pix & 0x7FFFFFFFu) | (diffuse ? 0x80000000u : 0u);
+                    }
                 }
             }
-            if (!alive) {
-                // the path ends here: its radiance sample goes to this iteration slot's plane; k_accumulate folds
-                // the planes into the running mean in iteration order once the launch sequence is done
-                float *lp = p.lbuf + 3u * ((size_t)(pix >> SLOT_SHIFT) * npix + (size_t)(pix & PIX_MASK));
-                lp[0] = L.x;
-                lp[1] = L.y;
-                lp[2] = L.z;
+        }
+        if (NEE) {
+            const uint64_t wmask = __ballot(want_shadow);
+            if (wmask != 0ull) {                              // wave-uniform
+                shadow_count += (uint32_t)__popcll(wmask);
+                const Hit hs = nearestHit<GEOM, false>(p, s_prims, s_nodes, wq, so, sd, want_shadow, (uint32_t)lane);
+                if (want_shadow && hs.any && hs.prim == lprim) {
+                    const float tol = 1e-3f * ((ldist > 1.0f) ? ldist : 1.0f);
+                    if (fabsf(hs.t - ldist) <= tol) L = L + Ld;          // the sampled point itself is what the ray reached
+                }
             }
+            if (valid) {
+                // the plane entry accumulates along the path: set at bounce 0, added to afterwards (exclusive owner)
+                float *lp = p.lbuf + 3u * ((size_t)((pix >> SLOT_SHIFT) & (uint32_t)(MAXSLOT - 1)) * npix + (size_t)(pix & PIX_MASK));
+                if (FIRST) {
+                    lp[0] = L.x;
+                    lp[1] = L.y;
+                    lp[2] = L.z;
+                } else if (L.x != 0.0f || L.y != 0.0f || L.z != 0.0f) {
+                    lp[0] = lp[0] + L.x;
+                    lp[1] = lp[1] + L.y;
+                    lp[2] = lp[2] + L.z;
+                }
+            }
+        } else if (valid && !alive) {
+            // the path ends here: its radiance sample goes to this iteration slot's plane; k_accumulate folds
+            // the planes into the running mean in iteration order once the launch sequence is done
+            float *lp = p.lbuf + 3u * ((size_t)(pix >> SLOT_SHIFT) * npix + (size_t)(pix & PIX_MASK));
+            lp[0] = L.x;
+            lp[1] = L.y;
+            lp[2] = L.z;
         }
 
         if (last) continue;      // wave-uniform: nothing survives the last bounce
@@ -574,6 +670,9 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
     }
     if (COMPACT == 0) {
         if (lane == 0 && live_count) atomicAdd(&st->counts[cnt_index(bounce, 0)], live_count);
+    }
+    if (NEE) {
+        if (lane == 0 && shadow_count) atomicAdd(&st->shadow_rays, (unsigned long long)shadow_count);
     }
     if (bounce == 1 && blockIdx.x == 0 && tid == 0) {      // clock diagnostics (one thread per launch)
         st->clk[0] = __builtin_amdgcn_s_memtime() - clk0;
@@ -757,30 +856,34 @@ static const void *bounce_fn(bool first)
 }
 
 template <int WG, int GEOM>
-static const void *bounce_fn_geom(bool first, int compact)
+static const void *bounce_fn_geom(bool first, int compact, int nee)
 {
+    if (nee) {
+        if (compact != 1) return nullptr;
+        return first ? (const void *)k_bounce<WG, true, GEOM, 1, true> : (const void *)k_bounce<WG, false, GEOM, 1, true>;
+    }
     if (compact == 1) return bounce_fn<WG, GEOM, 1>(first);
     if (compact == 2) return bounce_fn<WG, GEOM, 2>(first);
     return bounce_fn<WG, GEOM, 0>(first);
 }
 
 template <int WG>
-static const void *bounce_fn_wg(bool first, int geom, int compact)
+static const void *bounce_fn_wg(bool first, int geom, int compact, int nee)
 {
-    if (geom == GEOM_BVH) return bounce_fn_geom<WG, GEOM_BVH>(first, compact);
-    if (geom == GEOM_QUEUE) return bounce_fn_geom<WG, GEOM_QUEUE>(first, compact);
-    if (geom == GEOM_LDS) return bounce_fn_geom<WG, GEOM_LDS>(first, compact);
-    return bounce_fn_geom<WG, GEOM_SCALAR>(first, compact);
+    if (geom == GEOM_BVH) return bounce_fn_geom<WG, GEOM_BVH>(first, compact, nee);
+    if (geom == GEOM_QUEUE) return bounce_fn_geom<WG, GEOM_QUEUE>(first, compact, nee);
+    if (geom == GEOM_LDS) return bounce_fn_geom<WG, GEOM_LDS>(first, compact, nee);
+    return bounce_fn_geom<WG, GEOM_SCALAR>(first, compact, nee);
 }
 
 static const void *select_bounce(const LaunchCfg &cfg, bool first)
 {
     switch (cfg.workgroup) {
-    case 64: return bounce_fn_wg<64>(first, cfg.geom, cfg.compact);
-    case 128: return bounce_fn_wg<128>(first, cfg.geom, cfg.compact);
-    case 256: return bounce_fn_wg<256>(first, cfg.geom, cfg.compact);
-    case 512: return bounce_fn_wg<512>(first, cfg.geom, cfg.compact);
-    case 1024: return bounce_fn_wg<1024>(first, cfg.geom, cfg.compact);
+    case 64: return bounce_fn_wg<64>(first, cfg.geom, cfg.compact, cfg.nee);
+    case 128: return bounce_fn_wg<128>(first, cfg.geom, cfg.compact, cfg.nee);
+    case 256: return bounce_fn_wg<256>(first, cfg.geom, cfg.compact, cfg.nee);
+    case 512: return bounce_fn_wg<512>(first, cfg.geom, cfg.compact, cfg.nee);
+    case 1024: return bounce_fn_wg<1024>(first, cfg.geom, cfg.compact, cfg.nee);
     default: return nullptr;
     }
 }

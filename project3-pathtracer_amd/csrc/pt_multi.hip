@@ -222,6 +222,7 @@ int pt_multi_get_stats(pt_multi *m, pt_stats *out)
         for (int b = 0; b < PT_MAX_DEPTH; ++b) out->live_in[b] += s.live_in[b];
         if (s.gpu_ms > out->gpu_ms) out->gpu_ms = s.gpu_ms;        // devices run concurrently
         out->bounce_launches += s.bounce_launches;
+        out->shadow_rays += s.shadow_rays;
     }
     return PT_OK;
 }

@@ -60,7 +60,8 @@ class Fresnel(C.Structure):
 
 
 class Options(C.Structure):
-    _fields_ = [("depth", C.c_int), ("rr_start", C.c_int), ("seed", C.c_uint), ("trig_mode", C.c_int)]
+    _fields_ = [("depth", C.c_int), ("rr_start", C.c_int), ("seed", C.c_uint), ("trig_mode", C.c_int),
+                ("direct_light", C.c_int)]
 
 
 class Scene(C.Structure):
@@ -119,6 +120,10 @@ def lib():
         "o_clearImage": (None, [C.c_void_p, i]),
         "o_render": (i, [P(StaticGeom), i, P(Material), i, P(CameraData), P(Options), C.c_void_p, i, i,
                          C.c_void_p, i]),
+        "o_render_counted": (i, [P(StaticGeom), i, P(Material), i, P(CameraData), P(Options), C.c_void_p, i, i,
+                                 C.c_void_p, P(C.c_ulonglong), i]),
+        "o_lightArea": (f, [P(StaticGeom)]),
+        "o_sampleLight": (None, [P(StaticGeom), f, P(Vec3), P(Vec3)]),
         "o_trace_path": (Vec3, [P(StaticGeom), i, P(Material), i, P(CameraData), P(Options), i, i, u, P(i)]),
         "o_buildTransformationMatrix": (Mat4, [Vec3, Vec3, Vec3, i, P(Mat4)]),
         "o_camera_fov": (Vec2, [f, Vec2]),
@@ -208,19 +213,22 @@ class LoadedScene:
 
 
 def render(geoms, nG, mats, nM, cam, depth, iters=1, iter_first=1, rr_start=-1, seed=0, trig=TRIG_POLY,
-           image=None, nthreads=None):
-    """Returns (image[H,W,3] float32, live_in[depth] uint64)."""
+           image=None, nthreads=None, direct_light=0, shadow_out=None):
+    """Returns (image[H,W,3] float32, live_in[depth] uint64); shadow_out (a list) receives the shadow-ray count."""
     W, H = int(cam.resolution.x), int(cam.resolution.y)
     if image is None:
         image = np.zeros((H, W, 3), dtype=np.float32)
     else:
         image = np.ascontiguousarray(image, dtype=np.float32).copy()
     live = np.zeros(depth, dtype=np.uint64)
-    opt = Options(depth, rr_start, seed, trig)
+    opt = Options(depth, rr_start, seed, trig, direct_light)
     if nthreads is None:
         nthreads = os.cpu_count() or 1
-    rc = lib().o_render(geoms, nG, mats, nM, C.byref(cam), C.byref(opt), image.ctypes.data, iter_first, iters,
-                        live.ctypes.data, nthreads)
+    shadow = C.c_ulonglong(0)
+    rc = lib().o_render_counted(geoms, nG, mats, nM, C.byref(cam), C.byref(opt), image.ctypes.data, iter_first, iters,
+                                live.ctypes.data, C.byref(shadow), nthreads)
     if rc != 0:
         raise RuntimeError(f"o_render failed: {rc}")
+    if shadow_out is not None:
+        shadow_out.append(int(shadow.value))
     return image, live

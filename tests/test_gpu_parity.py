@@ -474,3 +474,53 @@ def test_multi_device_handle_matches_single_context(pkg, ndev):
         assert np.array_equal(host, ref5)
     finally:
         L.pt_multi_destroy(m)
+
+
+# ---------------------------------------------------------------- direct lighting
+def cpu_render_dl(scene, w, h, depth, iters=1, rotat=0, rr_start=-1):
+    sc = O.LoadedScene(os.path.join(SCENES, scene), rotat)
+    sc.set_resolution(w, h)
+    sh = []
+    img, live = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, depth, iters=iters,
+                         rr_start=rr_start, direct_light=1, shadow_out=sh)
+    return img, [int(x) for x in live], sh[0]
+
+
+@pytest.mark.parametrize("scene,rotat,depth,iters", [("sampleScene_spec.txt", 0, 5, 3), ("sampleScene.txt", 1, 4, 2),
+                                                     ("cornell_glass.txt", 1, 8, 2), ("sampleScene.txt", 1, 1, 2)])
+def test_direct_lighting_matches_oracle(pkg, scene, rotat, depth, iters):
+    """pt_options.direct_light: explicit light sampling (the reference's float-seeded samplers) + one shadow ray per
+    diffuse vertex.  Image, live-ray counts and the number of shadow rays equal the oracle's."""
+    W, H = 96, 64
+    cpu, lc, shadows = cpu_render_dl(scene, W, H, depth, iters=iters, rotat=rotat)
+    gpu, lg, st = gpu_render(pkg, scene, W, H, depth, iters=iters, rotat=rotat, direct_light=1)
+    check(gpu, cpu, lg, lc, f"direct lighting {scene} depth {depth}")
+    assert int(st.shadow_rays) == shadows and shadows > 0
+    plain, _, st0 = gpu_render(pkg, scene, W, H, depth, iters=iters, rotat=rotat)
+    assert int(st0.shadow_rays) == 0 and not np.array_equal(plain, gpu)
+
+
+@pytest.mark.parametrize("geom_path", [1, 2, 3, 4])
+def test_direct_lighting_on_every_geometry_path(pkg, geom_path):
+    W, H, depth = 80, 60, 4
+    cpu, lc, shadows = cpu_render_dl("sampleScene_spec.txt", W, H, depth, iters=2, rotat=1)
+    gpu, lg, st = gpu_render(pkg, "sampleScene_spec.txt", W, H, depth, iters=2, rotat=1, direct_light=1, geom_path=geom_path)
+    check(gpu, cpu, lg, lc, f"direct lighting geom_path {geom_path}")
+    assert int(st.shadow_rays) == shadows
+
+
+def test_direct_lighting_batching_rr_and_large_scene(pkg):
+    W, H = 64, 48
+    cpu, lc, shadows = cpu_render_dl("cloud256.txt", W, H, 6, iters=5, rotat=1, rr_start=2)
+    for batch in (1, 3, 8):
+        gpu, lg, st = gpu_render(pkg, "cloud256.txt", W, H, 6, iters=5, rotat=1, direct_light=1, rr_start=2, batch=batch)
+        check(gpu, cpu, lg, lc, f"direct lighting cloud256 batch {batch}")
+        assert int(st.shadow_rays) == shadows
+
+
+def test_direct_lighting_needs_compaction_1(pkg):
+    with pkg.Renderer(0) as r:
+        with pytest.raises(pkg.PtError):
+            r.set_options(direct_light=1, compaction=2)
+        with pytest.raises(pkg.PtError):
+            r.set_options(direct_light=2)
