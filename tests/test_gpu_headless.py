@@ -95,3 +95,21 @@ def test_headless_on_several_contexts(tmp_path):
     ref, _ = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, depth, iters=iters)
     q = np.clip(ref * np.float32(255.0), 0, 255).astype(np.uint8)[:, ::-1, :]
     assert np.array_equal(got, q)
+
+
+def test_headless_direct_lighting(tmp_path):
+    """PT_DIRECT_LIGHT=1 through the reference-signature entry point: the picture the oracle renders with explicit
+    light sampling."""
+    pkg = load_package()
+    W, H, depth, iters = 72, 48, 4, 6
+    scene = os.path.join(ROOT, "scenes", "sampleScene.txt")
+    env = dict(os.environ, PT_DEPTH=str(depth), PT_DIRECT_LIGHT="1")
+    res = subprocess.run([pkg.HEADLESS_PATH, f"scene={scene}", "frame=0", "rotat=degrees", f"res={W}x{H}", f"iterations={iters}",
+                          f"out={tmp_path}"], env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    got = read_bmp(os.path.join(tmp_path, "test.0.bmp"))
+    sc = O.LoadedScene(scene, 1)
+    sc.set_resolution(W, H)
+    ref, _ = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, depth, iters=iters, direct_light=1)
+    q = np.clip(ref * np.float32(255.0), 0, 255).astype(np.uint8)[:, ::-1, :]
+    assert np.array_equal(got, q)
