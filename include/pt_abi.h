@@ -97,7 +97,9 @@ typedef struct pt_options {
                              getRandomPointOnCube / getRandomPointOnSphere samplers, ref: src/intersections.h:133-182) and
                              do not count a light hit by chance after such a vertex; 0 = pure path tracing (default).
                              Needs compaction 1. */
-    int reserved[5];
+    int absorption;       /* 1 = Beer-Lambert absorption (material ABSCOEFF) over path segments that end on the inner side of
+                             a refractive surface: calculateTransmission, ref stub src/interactions.h:31-33; 0 = off (default) */
+    int reserved[4];
 } pt_options;
 
 typedef struct pt_stats {
@@ -180,7 +182,9 @@ enum {
     PT_KAT_POINT_ON_RAY = 10,   /* in: o[3], d[3], t                             out: p[3]                 ref src/intersections.h:46-48 */
     PT_KAT_REFLECT = 11,        /* in: normal[3], incident[3]                    out: dir[3]               ref src/interactions.h:47-50 */
     PT_KAT_REFRACT = 12,        /* in: normal[3], incident[3], n1, n2            out: dir[3] (0 on TIR)    ref src/interactions.h:42-44 */
-    PT_KAT_FRESNEL = 13         /* in: normal[3], incident[3], n1, n2, trans[3]  out: reflectance          ref src/interactions.h:53-59 */
+    PT_KAT_FRESNEL = 13,        /* in: normal[3], incident[3], n1, n2, trans[3]  out: reflectance          ref src/interactions.h:53-59 */
+    PT_KAT_TRANSMISSION = 14,   /* in: absorption[3], distance                   out: rgb transmittance    ref src/interactions.h:31-33 */
+    PT_KAT_SAMPLE_LIGHT = 15    /* in: type (bits), transform[16], seed          out: p[3], n[3]           direct lighting sampler */
 };
 int  pt_device_kat(pt_ctx *ctx, int op, const float *in, int n_in, float *out, int n_out);
 

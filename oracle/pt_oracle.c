@@ -364,6 +364,31 @@ o_vec3 o_getRandomDirectionInSphere(float xi1, float xi2, int trig_mode)
     return v3(rad * cs, rad * sn, z);
 }
 
+/* spec: deterministic exp built from fp32 + - * and floor only (Cody-Waite reduction by ln 2, cephes expf
+ * polynomial), so the HIP kernels and this oracle agree bit for bit; relative error < 2e-7 on [-87, 88]. */
+float o_exp_poly(float x)
+{
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    float kf = floorf(x * 1.44269504f + 0.5f);
+    int k = (int)kf;
+    float r = (x - kf * 0.693359375f) - kf * -2.12194440e-4f;
+    float z = r * r;
+    float p = ((((1.9875691500e-4f * r + 1.3981999507e-3f) * r + 8.3334519073e-3f) * r + 4.1665795894e-2f) * r
+               + 1.6666665459e-1f) * r + 5.0000001201e-1f;
+    float y = (p * z + r) + 1.0f;
+    union { unsigned u; float f; } s;
+    s.u = (unsigned)(k + 127) << 23;                     /* 2^k, k in [-126, 127] on the clamped range */
+    return y * s.f;
+}
+
+/* spec (ref stub: src/interactions.h:31-33): Beer-Lambert transmittance exp(-sigma_a * distance) per channel */
+o_vec3 o_calculateTransmission(o_vec3 absorptionCoefficient, float distance)
+{
+    return v3(o_exp_poly(-absorptionCoefficient.x * distance), o_exp_poly(-absorptionCoefficient.y * distance),
+              o_exp_poly(-absorptionCoefficient.z * distance));
+}
+
 /* spec (ref stub: src/interactions.h:47-50): mirror law d - 2(d.n)n */
 o_vec3 o_calculateReflectionDirection(o_vec3 normal, o_vec3 incident)
 {
@@ -562,7 +587,8 @@ static o_vec3 trace_path(const o_staticGeom *geoms, int nG, const o_material *ma
         if (bounces) (*bounces)++;
         if (live_in) live_in[b]++;
         o_vec3 p, n;
-        int hit = nearest_hit(geoms, nG, r, &p, &n, NULL);
+        float t_hit;
+        int hit = nearest_hit(geoms, nG, r, &p, &n, &t_hit);
         if (hit < 0) break;                                        /* background is black */
         const o_material *m = &mats[geoms[hit].materialid];
         if (m->emittance > 0.0f) {                                 /* light: emit and stop */
@@ -609,7 +635,25 @@ static o_vec3 trace_path(const o_staticGeom *geoms, int nG, const o_material *ma
         }
         if (b == opt->depth - 1) break;                            /* depth exhausted */
 
-        o_calculateBSDF(&r, p, n, &T, m, u_select, xi1, xi2, opt->trig_mode);
+        /* spec (optional): a segment that ends on the inner side of a refractive surface ran through
+         * the medium: Beer-Lambert with the material's ABSCOEFF over the segment's world length */
+        if (opt->absorption && m->hasRefractive > 0.0f && dot3(n, r.direction) > 0.0f &&
+            (m->absorptionCoefficient.x != 0.0f || m->absorptionCoefficient.y != 0.0f || m->absorptionCoefficient.z != 0.0f))
+            T = mul3(T, o_calculateTransmission(m->absorptionCoefficient, t_hit));
+
+        const o_vec3 d_in = r.direction;
+        int lobe = o_calculateBSDF(&r, p, n, &T, m, u_select, xi1, xi2, opt->trig_mode);
+        if (lobe == 2) {
+            /* spec: a transmitted ray must start on the far side of the surface, but `p` was pulled back towards
+             * the ray origin by getPointOnRay's 1e-4 object-space epsilon (ref: src/intersections.h:46-48), which
+             * for objects scaled by more than 2 exceeds RAY_BIAS_AMOUNT: the ray would meet the same surface
+             * again from the same side.  The offset therefore adds that pull-back's world length,
+             * 1e-4 / |inverseTransform * d|. */
+            o_vec3 v = o_multiplyMV(geoms[hit].inverseTransform, v4(d_in, 0.0f));
+            float pb = 1e-4f * (1.0f / sqrtf(dot3(v, v)));
+            o_vec3 nf = (dot3(n, d_in) > 0.0f) ? neg3(n) : n;
+            r.origin = add3(p, scale3(O_RAY_BIAS_AMOUNT + pb, neg3(nf)));
+        }
         suppress = nee && diffuse;
 
         if (opt->rr_start >= 0 && b >= opt->rr_start) {            /* Russian roulette */

@@ -64,7 +64,7 @@ class CameraData(C.Structure):
 class Options(C.Structure):
     _fields_ = [("depth", C.c_int), ("rr_start", C.c_int), ("seed", C.c_uint), ("compaction", C.c_int),
                 ("workgroup", C.c_int), ("geom_path", C.c_int), ("row_begin", C.c_int), ("row_end", C.c_int),
-                ("use_graph", C.c_int), ("batch", C.c_int), ("direct_light", C.c_int), ("reserved", C.c_int * 5)]
+                ("use_graph", C.c_int), ("batch", C.c_int), ("direct_light", C.c_int), ("absorption", C.c_int), ("reserved", C.c_int * 4)]
 
 
 class Stats(C.Structure):

@@ -116,7 +116,7 @@ struct BvhNode {
 static_assert(sizeof(BvhNode) == 32, "BvhNode must be 32 B");
 
 // Material planes (SoA): plane k of material id at mats[k * nM + id]
-enum { M_CR = 0, M_CG, M_CB, M_SR, M_SG, M_SB, M_REFL, M_REFR, M_IOR, M_EMIT, M_PLANES };
+enum { M_CR = 0, M_CG, M_CB, M_SR, M_SG, M_SB, M_REFL, M_REFR, M_IOR, M_EMIT, M_AR, M_AG, M_AB, M_PLANES };
 
 // ---------------------------------------------------------------------------------------------
 // RNG: Wang hash (ref: src/intersections.h:26-34) + thrust::minstd_rand + uniform_real_distribution<float>
@@ -421,6 +421,29 @@ __device__ __forceinline__ f3 getRandomPointOnSphere(const float *fwd, float ran
     const float xi1 = uniform_real(rng, 0, 1), xi2 = uniform_real(rng, 0, 1);
     const f3 d = getRandomDirectionInSphere(xi1, xi2);
     return mulMV(fwd, 0.5f * d, 1.0f);
+}
+
+// deterministic exp from fp32 + - * and floor only (Cody-Waite by ln 2 + cephes expf polynomial); the oracle runs the
+// same sequence, so results agree bit for bit
+__device__ __forceinline__ float exp_poly(float x)
+{
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    const float kf = floorf(x * 1.44269504f + 0.5f);
+    const int k = (int)kf;
+    const float r = (x - kf * 0.693359375f) - kf * -2.12194440e-4f;
+    const float z = r * r;
+    const float p = ((((1.9875691500e-4f * r + 1.3981999507e-3f) * r + 8.3334519073e-3f) * r + 4.1665795894e-2f) * r +
+                     1.6666665459e-1f) * r + 5.0000001201e-1f;
+    const float y = (p * z + r) + 1.0f;
+    return y * __uint_as_float((uint32_t)(k + 127) << 23);
+}
+
+// calculateTransmission (stub ref: src/interactions.h:31-33): Beer-Lambert transmittance per channel
+__device__ __forceinline__ f3 calculateTransmission(f3 absorptionCoefficient, float distance)
+{
+    return mk(exp_poly(-absorptionCoefficient.x * distance), exp_poly(-absorptionCoefficient.y * distance),
+              exp_poly(-absorptionCoefficient.z * distance));
 }
 
 // Direct lighting: a point on a light and the geometric normal there, from one float seed (the reference's sampler

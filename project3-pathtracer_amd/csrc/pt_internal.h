@@ -66,6 +66,7 @@ struct KParams {
     uint32_t segcap;       // slots per pool segment
     IterState *st;
     RayPool pool[2];
+    int absorption;        // 1 = Beer-Lambert absorption inside refractive objects (material planes M_AR..M_AB)
     int nlights;           // direct lighting: emissive primitives (0 = feature off), indices in `lights`
     const int *lights;
 };

@@ -553,6 +553,7 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
                     if (!last) {
                     f3 nd;
                     f3 bias_n = nf;
+                    float bias = 0.0002f;                 // RAY_BIAS_AMOUNT, ref: src/utilities.h:26
                     if (refr > 0.0f) {
                         const float ior = s_mats[M_IOR * p.nM + m];
                         const float n1 = backside ? ior : 1.0f;
@@ -561,9 +562,26 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
                         bool tir;
                         const f3 tdir = transmissionDirection(nf, d, n1, n2, tir);
                         const float Rf = fresnelReflectance(nf, d, n1, n2, tdir);
+                        if (p.absorption && backside) {
+                            // the segment that ends on the inner side of the surface ran through the medium
+                            const f3 sa = mk(s_mats[M_AR * p.nM + m], s_mats[M_AG * p.nM + m], s_mats[M_AB * p.nM + m]);
+                            if (sa.x != 0.0f || sa.y != 0.0f || sa.z != 0.0f) T = T * calculateTransmission(sa, h.t);
+                        }
                         T = T * mk(s_mats[M_SR * p.nM + m], s_mats[M_SG * p.nM + m], s_mats[M_SB * p.nM + m]);
                         if (u_select < Rf) nd = rdir;
-                        else { nd = tdir; bias_n = -nf; }
+                        else {
+                            // transmitted: start beyond the surface.  h.p was pulled back by getPointOnRay's 1e-4
+                            // object-space epsilon (ref: src/intersections.h:46-48) = 1e-4/|inverseTransform*d| in
+                            // world units, more than the bias for objects scaled by > 2
+                            nd = tdir;
+                            bias_n = -nf;
+                            const Prim *HP = PRIMS_IN_LDS ? &s_prims[h.prim] : &p.prims[h.prim];
+                            const float4 *iv = reinterpret_cast<const float4 *>(HP->inv);
+                            const float4 i0 = iv[0], i1 = iv[1], i2 = iv[2];
+                            const float inv[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
+                            const f3 v = mulMV(inv, d, 0.0f);
+                            bias = 0.0002f + 1e-4f * rsqrt_rn(dot(v, v));
+                        }
                     } else if (refl > 0.0f) {
                         T = T * mk(s_mats[M_SR * p.nM + m], s_mats[M_SG * p.nM + m], s_mats[M_SB * p.nM + m]);
                         nd = reflectionDirection(nf, d);
@@ -571,7 +589,7 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
                         T = T * mk(s_mats[M_CR * p.nM + m], s_mats[M_CG * p.nM + m], s_mats[M_CB * p.nM + m]);
                         nd = randomDirectionInHemisphere(nf, xi1, xi2);
                     }
-                    o = h.p + 0.0002f * bias_n;       // RAY_BIAS_AMOUNT, ref: src/utilities.h:26
+                    o = h.p + bias * bias_n;
                     d = nd;
                     alive = true;
                     if (p.rr_start >= 0 && bounce >= p.rr_start) {      // Russian roulette
@@ -746,6 +764,19 @@ __global__ void k_device_kat(int op, const float *in, float *out, int n_out)
     case PT_KAT_FRESNEL:
         out[0] = fresnelReflectance(mk(in[0], in[1], in[2]), mk(in[3], in[4], in[5]), in[6], in[7], mk(in[8], in[9], in[10]));
         break;
+    case PT_KAT_TRANSMISSION: {
+        const f3 t = calculateTransmission(mk(in[0], in[1], in[2]), in[3]);
+        out[0] = t.x; out[1] = t.y; out[2] = t.z;
+        break;
+    }
+    case PT_KAT_SAMPLE_LIGHT: {
+        float fwd[12];
+        for (int k = 0; k < 12; ++k) fwd[k] = in[1 + k];
+        f3 y, n;
+        sampleLight(__float_as_uint(in[0]), fwd, mulMV(fwd, mk(0, 0, 0), 1.0f), in[17], y, n);
+        out[0] = y.x; out[1] = y.y; out[2] = y.z; out[3] = n.x; out[4] = n.y; out[5] = n.z;
+        break;
+    }
     default: break;
     }
 }

@@ -12,6 +12,7 @@
 //   PT_DEPTH (8)          bounces per path (the reference's traceDepth, src/raytraceKernel.cu:110)
 //   PT_RR_START (-1)      first bounce with Russian roulette, -1 = off
 //   PT_DIRECT_LIGHT (0)   1 = sample the lights explicitly at diffuse vertices (getRandomPointOnCube / ...OnSphere)
+//   PT_ABSORPTION (0)     1 = Beer-Lambert absorption (ABSCOEFF) inside refractive objects (calculateTransmission)
 //   PT_SEED (0)           RNG stream selector
 //   PT_DEVICES (0)        comma-separated HIP devices; with several, each renders a band of rows of the frame
 //                         (pt_multi_*), the bands are gathered into renderCam->image; PBO output then needs 1 device
@@ -90,6 +91,7 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
         o.depth = env_int("PT_DEPTH", o.depth);
         o.rr_start = env_int("PT_RR_START", o.rr_start);
         o.direct_light = env_int("PT_DIRECT_LIGHT", o.direct_light);
+        o.absorption = env_int("PT_ABSORPTION", o.absorption);
         o.seed = (unsigned)env_int("PT_SEED", 0);
         check(pt_multi_set_options(g.ctx, &o), "pt_set_options");
         g.readback_every = env_int("PT_READBACK_EVERY", 0);

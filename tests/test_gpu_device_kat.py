@@ -142,3 +142,26 @@ def test_bad_kat_arguments(gpu):
         gpu.device_kat(99, [0.0], 1)
     with pytest.raises(pkg.PtError):
         gpu.device_kat(INTERSECT, [0.0] * 5, 7)
+
+
+TRANSMISSION, SAMPLE_LIGHT = 14, 15
+
+
+def test_transmission_and_light_sampler_against_oracle(gpu):
+    """calculateTransmission (deterministic exp) and the direct-lighting sampler on the device == the oracle."""
+    L = O.lib()
+    rng = np.random.default_rng(11)
+    for k in range(200):
+        sig = [float(np.float32(v)) for v in rng.uniform(0, 6, 3)]
+        dist = float(np.float32(10 ** rng.uniform(-4, 1.5)))
+        want = L.o_calculateTransmission(O.v3(sig), dist)
+        assert_bits(gpu.device_kat(TRANSMISSION, sig + [dist], 3), want.tup(), "calculateTransmission")
+    assert_bits(gpu.device_kat(TRANSMISSION, [0.0, 0.0, 1000.0, 1.0], 3), [1.0, 1.0, 0.0], "exp(0), underflow")
+    for k in range(60):
+        kind = O.CUBE if k % 2 else O.SPHERE
+        s = rng.uniform(0.3, 4, 3) if kind == O.CUBE else np.full(3, rng.uniform(0.3, 4))
+        g = O.make_geom(kind, 0, rng.uniform(-3, 3, 3), rng.uniform(-3, 3, 3), s)
+        p, n = O.Vec3(), O.Vec3()
+        L.o_sampleLight(C.byref(g), float(k * 37), C.byref(p), C.byref(n))
+        out = gpu.device_kat(SAMPLE_LIGHT, list(bits([kind])) + rows16(g.transform) + [float(k * 37)], 6)
+        assert_bits(out, p.tup() + n.tup(), "sampleLight")

@@ -524,3 +524,25 @@ def test_direct_lighting_needs_compaction_1(pkg):
             r.set_options(direct_light=1, compaction=2)
         with pytest.raises(pkg.PtError):
             r.set_options(direct_light=2)
+
+
+# ---------------------------------------------------------------- absorption inside refractive objects
+def test_absorption_in_glass_matches_oracle(pkg):
+    """pt_options.absorption: Beer-Lambert with the material's ABSCOEFF (.02 5.1 5.7 on the bundled glass) over segments
+    that end on the inner side of a refractive surface -- calculateTransmission with a deterministic exp."""
+    W, H, depth, iters = 96, 64, 8, 3
+    sc = O.LoadedScene(os.path.join(SCENES, "cornell_glass.txt"), 1)
+    sc.set_resolution(W, H)
+    cpu, lc = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, depth, iters=iters, absorption=1)
+    gpu, lg, _ = gpu_render(pkg, "cornell_glass.txt", W, H, depth, iters=iters, rotat=1, absorption=1)
+    check(gpu, cpu, lg, [int(x) for x in lc], "absorption in glass")
+    plain, lp, _ = gpu_render(pkg, "cornell_glass.txt", W, H, depth, iters=iters, rotat=1)
+    assert lp == lg and not np.array_equal(plain, gpu)          # same paths, tinted throughput
+    assert gpu.sum() < plain.sum()
+    # together with direct lighting and Russian roulette (throughput now steers path lengths)
+    sh = []
+    cpu2, lc2 = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, depth, iters=iters, absorption=1,
+                         direct_light=1, rr_start=1, shadow_out=sh)
+    gpu2, lg2, st2 = gpu_render(pkg, "cornell_glass.txt", W, H, depth, iters=iters, rotat=1, absorption=1, direct_light=1, rr_start=1)
+    check(gpu2, cpu2, lg2, [int(x) for x in lc2], "absorption + direct lighting + RR")
+    assert int(st2.shadow_rays) == sh[0]

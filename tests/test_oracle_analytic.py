@@ -349,3 +349,46 @@ def test_direct_lighting_off_without_lights_or_flag():
     sh = []
     b, lb = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, 4, iters=2, direct_light=1, shadow_out=sh)
     assert sh[0] == 0 and not b.any()
+
+
+def test_exp_poly_and_transmission():
+    """The deterministic exp is within 1.5e-7 (relative) of libm on its whole range; transmission is Beer-Lambert."""
+    L = O.lib()
+    xs = np.concatenate([np.linspace(-87, 88, 20001), -np.logspace(-8, 1.9, 500), [0.0, -0.0]]).astype(np.float32)
+    for x in xs:
+        assert abs(L.o_exp_poly(float(x)) - math.exp(float(x))) <= 1.5e-7 * math.exp(float(x))
+    assert L.o_exp_poly(-0.0) == 1.0 and L.o_exp_poly(-1000.0) == 0.0
+    t = L.o_calculateTransmission(O.v3(0.02, 5.1, 5.7), 0.5)
+    assert np.allclose(t.tup(), np.exp(-np.array([0.02, 5.1, 5.7]) * 0.5), rtol=1e-6)
+
+
+def test_absorption_only_acts_inside_refractive_objects():
+    sc = O.LoadedScene(os.path.join(SCENES, "sampleScene.txt"), 1)       # no refractive object in this scene
+    sc.set_resolution(24, 24)
+    a, _ = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, 4, iters=2)
+    b, _ = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, 4, iters=2, absorption=1)
+    assert np.array_equal(a, b)
+    g = O.LoadedScene(os.path.join(SCENES, "cornell_glass.txt"), 1)
+    g.set_resolution(32, 32)
+    a, la = O.render(g.geoms, g.n_objects, g.mats, g.n_materials, g.camera, 6, iters=4)
+    b, lb = O.render(g.geoms, g.n_objects, g.mats, g.n_materials, g.camera, 6, iters=4, absorption=1)
+    assert np.array_equal(la, lb) and (b <= a + 1e-6).all() and b.sum() < a.sum()
+
+
+@pytest.mark.parametrize("scale", [1.0, 4.0, 9.0])
+def test_transmitted_rays_cross_scaled_objects(scale):
+    """A ray through the centre of an index-matched (ior 1, so R = 0 and no bending) sphere or cube of any size reaches
+    the light behind it in exactly three vertices -- enter, leave, light -- with the light's full radiance.  (With a
+    fixed 0.0002 offset the transmitted ray of an object scaled by more than 2 would meet the entry surface again.)"""
+    L = O.lib()
+    mats = (O.Material * 2)(O.make_material(color=(0, 0, 0), refr=1.0, ior=1.0),
+                            O.make_material(color=(1, 0.5, 0.25), emittance=3.0))
+    cam = O.make_camera(1, 1, (0, 0, 20), (0, 0, -1), (0, 1, 0), 1.0)
+    for kind in (O.SPHERE, O.CUBE):
+        geoms = (O.StaticGeom * 2)(O.make_geom(kind, 0, (0, 0, 0), (0, 0, 0), (scale, scale, scale)),
+                                   O.make_geom(O.CUBE, 1, (0, 0, -12), (0, 0, 0), (30, 30, 0.5)))
+        for depth, want in ((3, (3.0, 1.5, 0.75)), (2, (0.0, 0.0, 0.0))):
+            opt = O.Options(depth, -1, 0, O.TRIG_POLY)
+            nb = C.c_int(0)
+            v = L.o_trace_path(geoms, 2, mats, 2, C.byref(cam), C.byref(opt), 0, 0, 1, C.byref(nb))
+            assert v.tup() == want and nb.value == depth, (kind, scale, depth, v.tup(), nb.value)
