@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--compaction", type=int, default=1, help="1 per-wave sharded (default), 2 workgroup scan, 0 off")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--direct-light", action="store_true", help="explicit light sampling (not the headline workload)")
+    ap.add_argument("--bands", action="store_true", help="N>1: one contiguous row band per rank instead of interleaved 8-row strips")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
@@ -128,16 +129,25 @@ def main():
     from project3_pathtracer_amd import sharding
     W, Hfull = sharding.weak_scaled_frame(args.width, args.height, world)
     sc.set_resolution(W, Hfull)
+    # N>1: interleaved 8-row strips (strip k -> rank k % N) so that every rank sees the same mix of ceiling, walls
+    # and floor; --bands switches to one contiguous band per rank (up to ~9 % slower at N=8: the bands differ in
+    # path length)
+    strips = world > 1 and not args.bands
     r0, r1 = sharding.band_rows(Hfull, world, rank)
-    Hband = r1 - r0
-    Hmax = sharding.max_band_rows(Hfull, world)
+    if strips:
+        Hband = sharding.strip_local_rows(Hfull, world, rank)
+        Hmax = sharding.max_strip_rows(Hfull, world)
+    else:
+        Hband = r1 - r0
+        Hmax = sharding.max_band_rows(Hfull, world)
 
     fb = torch.zeros((Hmax, W, 3), dtype=torch.float32, device=dev)
     r = pkg.Renderer(dev_index)
     r.set_options(depth=args.depth, rr_start=args.rr_start, workgroup=args.workgroup, geom_path=args.geom_path,
                   compaction=0 if args.no_compaction else args.compaction, batch=args.batch, use_graph=0 if args.no_graph else 1,
-                  row_begin=r0 if world > 1 else 0, row_end=r1 if world > 1 else 0,
-                  direct_light=1 if args.direct_light else 0)
+                  row_begin=r0 if (world > 1 and not strips) else 0, row_end=r1 if (world > 1 and not strips) else 0,
+                  strip_rows=sharding.STRIP_ROWS if strips else 0, strip_world=world if strips else 0,
+                  strip_rank=rank if strips else 0, direct_light=1 if args.direct_light else 0)
     r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
     r.set_camera(sc.camera)
     r.bind_image(fb.data_ptr())
@@ -149,10 +159,10 @@ def main():
             dist.barrier(device_ids=[dev_index])
 
     def gather():
+        fn = sharding.gather_strips if strips else sharding.gather_bands
         if rehearsal:      # gloo moves host tensors
-            host = sharding.gather_bands(fb.cpu(), Hfull, world, rank, dist=dist, dst=0)
-            return host
-        return sharding.gather_bands(fb, Hfull, world, rank, dist=dist, dst=0)       # RCCL over xGMI
+            return fn(fb.cpu(), Hfull, world, rank, dist=dist, dst=0)
+        return fn(fb, Hfull, world, rank, dist=dist, dst=0)       # RCCL over xGMI
 
     def sync():
         r.synchronize()
@@ -213,6 +223,7 @@ def main():
                     traffic = json.load(f).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        tile_note = ", interleaved 8-row strips" if strips else ""
         out = {
             "metric": "ray-bounces/sec",
             "value": rb_total / dt_max / 1e6,
@@ -227,12 +238,12 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.scene} {W}x{Hfull} ({world} row band(s) of ~{W}x{Hmax}), {args.steps} spp, "
+                "workload": f"{args.scene} {W}x{Hfull} ({world} tile(s) of ~{W}x{Hmax} rows{tile_note}), {args.steps} spp, "
                             f"{args.depth} bounces, diffuse+specular, rotat={args.rotat}, rr_start={args.rr_start}",
                 "scene": args.scene, "width": W, "height": Hfull, "depth": args.depth, "spp": args.steps,
                 "rotat_units": args.rotat, "primitives": sc.n_objects, "materials": sc.n_materials,
                 "compaction": 0 if args.no_compaction else args.compaction, "iteration_batch": args.batch or 8, "hip_graph": not args.no_graph, "direct_light": bool(args.direct_light),
-                "parallelism": f"pixel-bands x{world}" + (", 1 RCCL gather" if world > 1 else ""),
+                "parallelism": (f"pixel-strips x{world}" if strips else f"pixel-bands x{world}") + (", 1 RCCL gather" if world > 1 else ""),
             },
             "ray_bounces": int(rb_total),
             "shadow_rays": int(st.shadow_rays),

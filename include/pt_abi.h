@@ -99,7 +99,11 @@ typedef struct pt_options {
                              Needs compaction 1. */
     int absorption;       /* 1 = Beer-Lambert absorption (material ABSCOEFF) over path segments that end on the inner side of
                              a refractive surface: calculateTransmission, ref stub src/interactions.h:31-33; 0 = off (default) */
-    int reserved[4];
+    int strip_rows;       /* > 0: interleaved row strips instead of one band -- the frame is cut into strips of strip_rows */
+    int strip_world;      /*   rows, strip k belongs to context k % strip_world, and this context (strip_rank) renders its */
+    int strip_rank;       /*   strips packed in order (balances ranks when path lengths vary down the frame); row_begin =
+                               row_end = 0 then.  pt_strip_local_rows / pt_strip_global_row give the mapping.  0 = off */
+    int reserved[1];
 } pt_options;
 
 typedef struct pt_stats {
@@ -112,6 +116,10 @@ typedef struct pt_stats {
 } pt_stats;
 
 typedef struct pt_ctx pt_ctx;
+
+/* interleaved-strip tiles (pt_options.strip_*): rows a rank owns, and the frame row of its local row */
+int  pt_strip_local_rows(int height, int strip_rows, int world, int rank);
+int  pt_strip_global_row(int strip_rows, int world, int rank, int local_row);
 
 /* ---- lifetime ---- */
 int  pt_device_count(void);
@@ -220,6 +228,7 @@ int  pt_multi_render(pt_multi *m, int iter_first, int iter_count);  /* asynchron
 int  pt_multi_synchronize(pt_multi *m);
 int  pt_multi_download_image(pt_multi *m, float *host_rgb_full_frame);
 int  pt_multi_gather_to_device(pt_multi *m, void *device_rgb_full_frame, int dst_device);
+int  pt_multi_set_strips(pt_multi *m, int strip_rows);   /* > 0: interleaved strips (device k: strips k, k+n, ...); 0: bands */
 int  pt_multi_send_image_to_pbo(pt_multi *m, pt_uchar4 *device_pbo);  /* single-device handles only */
 int  pt_multi_get_stats(pt_multi *m, pt_stats *out);                /* sums over devices (gpu_ms: max) */
 

@@ -64,7 +64,8 @@ class CameraData(C.Structure):
 class Options(C.Structure):
     _fields_ = [("depth", C.c_int), ("rr_start", C.c_int), ("seed", C.c_uint), ("compaction", C.c_int),
                 ("workgroup", C.c_int), ("geom_path", C.c_int), ("row_begin", C.c_int), ("row_end", C.c_int),
-                ("use_graph", C.c_int), ("batch", C.c_int), ("direct_light", C.c_int), ("absorption", C.c_int), ("reserved", C.c_int * 4)]
+                ("use_graph", C.c_int), ("batch", C.c_int), ("direct_light", C.c_int), ("absorption", C.c_int), ("strip_rows", C.c_int), ("strip_world", C.c_int),
+                ("strip_rank", C.c_int), ("reserved", C.c_int * 1)]
 
 
 class Stats(C.Structure):
@@ -107,6 +108,8 @@ def lib():
     P = C.POINTER
     sig = {
         "pt_device_count": (i, []),
+        "pt_strip_local_rows": (i, [i, i, i, i]),
+        "pt_strip_global_row": (i, [i, i, i, i]),
         "pt_create": (i, [i, P(vp)]),
         "pt_destroy": (None, [vp]),
         "pt_last_error": (cp, []),
@@ -134,6 +137,7 @@ def lib():
         "pt_multi_synchronize": (i, [vp]),
         "pt_multi_download_image": (i, [vp, vp]),
         "pt_multi_gather_to_device": (i, [vp, vp, i]),
+        "pt_multi_set_strips": (i, [vp, i]),
         "pt_multi_send_image_to_pbo": (i, [vp, vp]),
         "pt_multi_get_stats": (i, [vp, P(Stats)]),
         "pt_upload_image": (i, [vp, vp]),

@@ -183,7 +183,13 @@ int configure(pt_ctx *c)
     int r0 = o.row_begin, r1 = o.row_end;
     if (r0 == 0 && r1 == 0) r1 = H;
     if (r0 < 0 || r1 > H || r0 >= r1) return fail(PT_ERR_INVALID, "tile rows [%d,%d) outside frame height %d", r0, r1, H);
-    const long long npix_ll = (long long)W * (long long)(r1 - r0);
+    int tile_rows = r1 - r0;
+    if (o.strip_rows > 0) {
+        tile_rows = pt_strip_local_rows(H, o.strip_rows, o.strip_world, o.strip_rank);
+        if (tile_rows < 1) return fail(PT_ERR_INVALID, "rank %d of %d owns no strip of %d rows in a frame of height %d",
+                                       o.strip_rank, o.strip_world, o.strip_rows, H);
+    }
+    const long long npix_ll = (long long)W * (long long)tile_rows;
     if ((long long)W * (long long)H > 0x7FFFFFFFLL / 4) return fail(PT_ERR_INVALID, "frame %dx%d too large", W, H);
     const int npix = (int)npix_ll;
 
@@ -212,6 +218,16 @@ int configure(pt_ctx *c)
     k.row_begin = r0;
     k.npix = npix;
     k.pix_offset = (uint32_t)r0 * (uint32_t)W;
+    if (o.strip_rows > 0) {
+        k.strip_rows = (uint32_t)o.strip_rows; k.strip_world = (uint32_t)o.strip_world; k.strip_rank = (uint32_t)o.strip_rank;
+        k.strip_span = (uint32_t)W * (uint32_t)o.strip_rows;
+        // division by strip_span as multiply + shift, exact for every tile-local pixel index (< 2^28):
+        // s = 28 + ceil(log2 span), m = ceil(2^s / span) < 2^29, and m*span - 2^s < span <= 2^(s-28)
+        uint32_t lg = 0;
+        while ((1ull << lg) < (unsigned long long)k.strip_span) ++lg;
+        k.strip_shift = 28u + lg;
+        k.strip_magic = (uint32_t)(((1ull << k.strip_shift) + k.strip_span - 1ull) / k.strip_span);
+    }
     k.nG = (int)c->geoms.size();
     k.nM = (int)c->mats.size();
     k.depth = o.depth;
@@ -476,6 +492,25 @@ extern "C" {
 const char *pt_last_error(void) { return g_last_error.c_str(); }
 const char *pt_version(void) { return "ptamd 0.1 (gfx950, abi 1)"; }
 
+int pt_strip_local_rows(int height, int strip_rows, int world, int rank)
+{
+    if (height < 1 || strip_rows < 1 || world < 1 || rank < 0 || rank >= world) return 0;
+    const long long nstrips = ((long long)height + strip_rows - 1) / strip_rows;      // the last one may be short
+    long long rows = 0;
+    for (long long k = rank; k < nstrips; k += world) {
+        const long long left = (long long)height - k * strip_rows;
+        rows += left < strip_rows ? left : strip_rows;
+    }
+    return (int)rows;
+}
+
+int pt_strip_global_row(int strip_rows, int world, int rank, int local_row)
+{
+    if (strip_rows < 1 || world < 1 || rank < 0 || rank >= world || local_row < 0) return -1;
+    const int j = local_row / strip_rows, w = local_row % strip_rows;
+    return (j * world + rank) * strip_rows + w;
+}
+
 int pt_device_count(void)
 {
     int n = 0;
@@ -558,6 +593,10 @@ int pt_set_options(pt_ctx *c, const pt_options *o)
         return fail(PT_ERR_INVALID, "workgroup %d not one of 0,64,128,256,512,1024", wg);
     if (o->geom_path < 0 || o->geom_path > 4) return fail(PT_ERR_INVALID, "geom_path %d not in 0..4", o->geom_path);
     if (o->row_begin < 0 || o->row_end < o->row_begin) return fail(PT_ERR_INVALID, "tile rows [%d,%d)", o->row_begin, o->row_end);
+    if (o->strip_rows < 0 || (o->strip_rows > 0 && (o->strip_world < 1 || o->strip_rank < 0 || o->strip_rank >= o->strip_world)))
+        return fail(PT_ERR_INVALID, "strips: rows %d, rank %d of %d", o->strip_rows, o->strip_rank, o->strip_world);
+    if (o->strip_rows > 0 && (o->row_begin != 0 || o->row_end != 0))
+        return fail(PT_ERR_INVALID, "strip tiles and a row band [%d,%d) exclude each other", o->row_begin, o->row_end);
     if (o->batch < 0 || o->batch > pt::PT_MAX_BATCH) return fail(PT_ERR_INVALID, "batch %d not in 0..%d", o->batch, pt::PT_MAX_BATCH);
     if (o->compaction < 0 || o->compaction > 2) return fail(PT_ERR_INVALID, "compaction %d not 0, 1 or 2", o->compaction);
     if (o->direct_light < 0 || o->direct_light > 1) return fail(PT_ERR_INVALID, "direct_light %d not 0 or 1", o->direct_light);
@@ -621,7 +660,10 @@ size_t pt_image_bytes(pt_ctx *c)
     int r0 = c->opt.row_begin, r1 = c->opt.row_end;
     if (r0 == 0 && r1 == 0) r1 = H;
     if (r1 > H || r0 >= r1) return 0;
-    return (size_t)W * (size_t)(r1 - r0) * 3 * sizeof(float);
+    int rows = r1 - r0;
+    if (c->opt.strip_rows > 0) rows = pt_strip_local_rows(H, c->opt.strip_rows, c->opt.strip_world, c->opt.strip_rank);
+    if (rows < 1) return 0;
+    return (size_t)W * (size_t)rows * 3 * sizeof(float);
 }
 
 int pt_bind_image(pt_ctx *c, void *device_rgb)
@@ -838,6 +880,10 @@ int pt_get_stats(pt_ctx *c, pt_stats *out)
                 (double)h.clk[0] / (double)h.clk[1] * 100.0);
     out->bounce_launches = c->bounce_launches;
     out->shadow_rays = h.shadow_rays;
+    if (getenv("PT_DEBUG_CLOCK") && h.dbg[2])
+        fprintf(stderr, "[ptamd] hierarchy walk: %.1f nodes, %.2f leaves per ray; per wave (longest lane): %.1f nodes, %.2f leaves, %.2f rounds\n",
+                (double)h.dbg[0] / (double)h.dbg[2], (double)h.dbg[1] / (double)h.dbg[2], (double)h.dbg[3] / (double)h.dbg[6],
+                (double)h.dbg[4] / (double)h.dbg[6], (double)h.dbg[5] / (double)h.dbg[6]);
     return PT_OK;
 }
 

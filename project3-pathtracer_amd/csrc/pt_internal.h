@@ -37,6 +37,7 @@ struct IterState {
     unsigned long long iterations;
     unsigned long long clk[4];                   // diagnostics: shader-clock / real-time ticks spent by workgroup 0 of the last bounce-1 launch
     unsigned long long shadow_rays;              // shadow rays cast (direct lighting), stats
+    unsigned long long dbg[8];                   // hierarchy-walk diagnostics (DEBUG_BVH builds only)
 };
 
 struct KParams {
@@ -66,6 +67,11 @@ struct KParams {
     uint32_t segcap;       // slots per pool segment
     IterState *st;
     RayPool pool[2];
+    // interleaved-strip tiles: local pixel pl -> global pixel pl + strip_span*(j*(strip_world-1) + strip_rank), j = pl/strip_span
+    uint32_t strip_span;   // W * strip_rows, 0 = contiguous band (pix_offset)
+    uint32_t strip_rows, strip_world, strip_rank;
+    uint32_t strip_magic;  // j = (pl * strip_magic) >> strip_shift, exact for pl < 2^28
+    uint32_t strip_shift;
     int absorption;        // 1 = Beer-Lambert absorption inside refractive objects (material planes M_AR..M_AB)
     int nlights;           // direct lighting: emissive primitives (0 = feature off), indices in `lights`
     const int *lights;

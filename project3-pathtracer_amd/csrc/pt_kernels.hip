@@ -25,6 +25,7 @@ using namespace ptd;
 
 static constexpr uint32_t DEAD = 0xFFFFFFFFu;
 static constexpr bool DEBUG_CULL = false;
+static constexpr bool DEBUG_BVH = false;         // count node / leaf visits of the hierarchy walk into IterState::dbg
 static constexpr int MAXSLOT = 8;                 // iterations in flight per launch sequence (pt_internal.h PT_MAX_BATCH)
 static constexpr uint32_t SLOT_SHIFT = 28;        // pixel word = tile-local pixel | slot << 28
 static constexpr uint32_t PIX_MASK = (1u << SLOT_SHIFT) - 1u;
@@ -162,11 +163,14 @@ __device__ __forceinline__ Hit nearestHitBvh(const KParams &p, const Prim *s_pri
     }
     uint32_t i = 0;
     const uint32_t nn = (uint32_t)p.nnodes;
+    uint32_t dbg_nodes = 0, dbg_leaves = 0, dbg_outer = 0, dbg_inner_wave = 0;
     for (;;) {
         // walk to the next leaf this ray can reach (box tests only), so that the lanes of the wave then run the
         // long exact test together instead of one lane at a time
         int prim = -1;
+        if (DEBUG_BVH) dbg_outer++;
         while (i < nn) {
+            if (DEBUG_BVH) dbg_nodes++;
             const float4 a = s_nodes[2 * i], b = s_nodes[2 * i + 1];
             const float x0 = (a.x - o.x) * ix, x1 = (b.x - o.x) * ix;
             const float y0 = (a.y - o.y) * iy, y1 = (b.y - o.y) * iy;
@@ -183,6 +187,7 @@ __device__ __forceinline__ Hit nearestHitBvh(const KParams &p, const Prim *s_pri
             if (prim >= 0) break;
         }
         if (prim < 0) break;
+        if (DEBUG_BVH) dbg_leaves++;
         const Prim &P = s_prims[prim];                     // per-lane gather from the LDS copy
         f3 ip, in;
         const float t = intersectPrim<false>(P, o, d, o, ip, in);
@@ -194,6 +199,25 @@ __device__ __forceinline__ Hit nearestHitBvh(const KParams &p, const Prim *s_pri
             h.n = in;
             h.material = P.material;
         }
+    }
+    if (DEBUG_BVH) {
+        // per ray: nodes, leaves; per wave: the longest lane (what the wave pays)
+        uint32_t mn = dbg_nodes, ml = dbg_leaves, mo = dbg_outer;
+        for (int s = 32; s > 0; s >>= 1) {
+            mn = max(mn, (uint32_t)__shfl_xor((int)mn, s));
+            ml = max(ml, (uint32_t)__shfl_xor((int)ml, s));
+            mo = max(mo, (uint32_t)__shfl_xor((int)mo, s));
+        }
+        atomicAdd(&p.st->dbg[0], (unsigned long long)dbg_nodes);
+        atomicAdd(&p.st->dbg[1], (unsigned long long)dbg_leaves);
+        atomicAdd(&p.st->dbg[2], 1ull);
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {
+            atomicAdd(&p.st->dbg[3], (unsigned long long)mn);
+            atomicAdd(&p.st->dbg[4], (unsigned long long)ml);
+            atomicAdd(&p.st->dbg[5], (unsigned long long)mo);
+            atomicAdd(&p.st->dbg[6], 1ull);
+        }
+        (void)dbg_inner_wave;
     }
     h.prim = best_g;
     h.t = best_t;
@@ -334,6 +358,14 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const Prim *s_prims,
     return h;
 }
 
+// global pixel index (x + y*W of the frame: what the RNG streams are keyed on) of tile-local pixel pl
+__device__ __forceinline__ uint32_t globalPixel(const KParams &p, uint32_t pl)
+{
+    if (p.strip_span == 0u) return pl + p.pix_offset;
+    const uint32_t j = (uint32_t)(((unsigned long long)pl * p.strip_magic) >> p.strip_shift);     // pl / strip_span
+    return pl + p.strip_span * (j * (p.strip_world - 1u) + p.strip_rank);
+}
+
 // COMPACT: 0 = rays keep their slot (validation / ablation), 1 = per-wave reservation on sharded counters
 // (no workgroup barrier), 2 = LDS scan over the workgroup's waves + one atomic per workgroup.
 // NEE: explicit light sampling at diffuse vertices (pt_options.direct_light).  A ray then carries in bit 31 of its
@@ -443,9 +475,9 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
                 for (uint32_t k = 1; k < (uint32_t)MAXSLOT; ++k) slot += (i >= k * npix) ? 1u : 0u;
                 const uint32_t pl = i - slot * npix;
                 pix = pl | (slot << SLOT_SHIFT);
-                const uint32_t gp = pl + p.pix_offset;
+                const uint32_t gp = globalPixel(p, pl);
                 const uint32_t x = pl % (uint32_t)p.W;
-                const uint32_t y = (uint32_t)p.row_begin + pl / (uint32_t)p.W;
+                const uint32_t y = gp / (uint32_t)p.W;
                 uint32_t kc = key_cam[0];
 #pragma unroll
                 for (uint32_t k = 1; k < (uint32_t)MAXSLOT; ++k) kc = (slot == k) ? key_cam[k] : kc;
@@ -501,7 +533,7 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
                     uint32_t kb = key_bounce[0];
 #pragma unroll
                     for (uint32_t k = 1; k < (uint32_t)MAXSLOT; ++k) kb = (slot == k) ? key_bounce[k] : kb;
-                    uint32_t s = minstd_seed(wang_hash(((pix & PIX_MASK) + p.pix_offset) ^ kb));
+                    uint32_t s = minstd_seed(wang_hash(globalPixel(p, pix & PIX_MASK) ^ kb));
                     s = minstd_next(s);
                     const float u_select = u01_of(s);
                     s = minstd_next(s);

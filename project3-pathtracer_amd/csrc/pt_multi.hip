@@ -23,6 +23,7 @@ struct pt_multi {
     pt_camera_data cam;
     bool have_cam = false;
     int height = 0, width = 0;
+    int strip = 0;             // > 0: interleaved strips of this many rows instead of one band per device
 };
 
 namespace {
@@ -37,9 +38,50 @@ int apply_options(pt_multi *m)
     const int n = (int)m->ctx.size();
     for (int k = 0; k < n; ++k) {
         pt_options o = m->opt;
-        if (m->have_cam && n > 1) band(m->height, n, k, &o.row_begin, &o.row_end);
+        o.strip_rows = o.strip_world = o.strip_rank = 0;
+        if (m->have_cam && n > 1) {
+            if (m->strip > 0) { o.strip_rows = m->strip; o.strip_world = n; o.strip_rank = k; o.row_begin = o.row_end = 0; }
+            else band(m->height, n, k, &o.row_begin, &o.row_end);
+        }
         int rc = pt_set_options(m->ctx[(size_t)k], &o);
         if (rc != PT_OK) return rc;
+    }
+    return PT_OK;
+}
+// Interleaved strips <-> one frame: device k's tile holds its strips packed, so tile -> frame is a strided 2-D copy
+// (row = one strip, source pitch = strip bytes, destination pitch = n strips) plus the short last strip if it has one.
+// host_frame != nullptr: frame in host memory; else frame on device `dst_device`.  to_frame=false: frame -> tiles (host).
+int copy_strips(pt_multi *m, float *host_frame, void *device_frame, int dst_device, bool to_frame)
+{
+    const int n = (int)m->ctx.size(), S = m->strip, H = m->height;
+    const size_t rowb = (size_t)m->width * 3 * sizeof(float), stripb = rowb * (size_t)S;
+    int rc = pt_multi_synchronize(m);
+    if (rc != PT_OK) return rc;
+    char *frame = host_frame ? (char *)host_frame : (char *)device_frame;
+    for (int k = 0; k < n; ++k) {
+        void *tile = nullptr;
+        rc = pt_image_device_pointer(m->ctx[(size_t)k], &tile);
+        if (rc != PT_OK) return rc;
+        if (hipSetDevice(m->device[(size_t)k]) != hipSuccess) return PT_ERR_HIP;
+        const int nstrips = (H + S - 1) / S;
+        int full = 0, tail_rows = 0, tail_strip = -1;
+        for (int j = k; j < nstrips; j += n) {
+            if ((j + 1) * S <= H) ++full;
+            else { tail_rows = H - j * S; tail_strip = j; }
+        }
+        char *f0 = frame + (size_t)k * stripb;                      // first strip of device k in the frame
+        const hipMemcpyKind kind = host_frame ? (to_frame ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice) : hipMemcpyDefault;
+        hipError_t e = hipSuccess;
+        if (full > 0) {
+            if (to_frame) e = hipMemcpy2D(f0, stripb * (size_t)n, tile, stripb, stripb, (size_t)full, kind);
+            else e = hipMemcpy2D(tile, stripb, f0, stripb * (size_t)n, stripb, (size_t)full, kind);
+        }
+        if (e == hipSuccess && tail_rows > 0) {
+            char *ft = frame + (size_t)tail_strip * stripb, *tt = (char *)tile + (size_t)full * stripb;
+            e = to_frame ? hipMemcpy(ft, tt, rowb * (size_t)tail_rows, kind) : hipMemcpy(tt, ft, rowb * (size_t)tail_rows, kind);
+        }
+        if (e != hipSuccess) return PT_ERR_HIP;
+        (void)dst_device;
     }
     return PT_OK;
 }
@@ -77,6 +119,17 @@ void pt_multi_destroy(pt_multi *m)
 
 int pt_multi_count(const pt_multi *m) { return m ? (int)m->ctx.size() : 0; }
 
+// strip_rows > 0: device k renders strips k, k+n, k+2n, ... of strip_rows rows each (balances the devices when path
+// lengths vary down the frame); 0: one contiguous band per device (default)
+int pt_multi_set_strips(pt_multi *m, int strip_rows)
+{
+    if (!m || strip_rows < 0) return PT_ERR_INVALID;
+    if (strip_rows > 0 && m->have_cam && (long long)strip_rows * (long long)m->ctx.size() > (long long)m->height + strip_rows - 1)
+        return PT_ERR_INVALID;                     // some device would own no strip
+    m->strip = strip_rows;
+    return apply_options(m);
+}
+
 int pt_multi_set_options(pt_multi *m, const pt_options *o)
 {
     if (!m || !o) return PT_ERR_INVALID;
@@ -99,6 +152,7 @@ int pt_multi_set_camera(pt_multi *m, const pt_camera_data *cam)
     if (!m || !cam) return PT_ERR_INVALID;
     const int H = (int)cam->resolution.y, W = (int)cam->resolution.x;
     if (H < (int)m->ctx.size() || W < 1) return PT_ERR_INVALID;          // every device needs at least one row
+    if (m->strip > 0 && (long long)m->strip * (long long)m->ctx.size() > (long long)H + m->strip - 1) return PT_ERR_INVALID;
     m->cam = *cam;
     m->have_cam = true;
     m->height = H;
@@ -112,7 +166,7 @@ int pt_multi_set_camera(pt_multi *m, const pt_camera_data *cam)
 
 int pt_multi_band(const pt_multi *m, int k, int *row_begin, int *row_end)
 {
-    if (!m || !m->have_cam || k < 0 || k >= (int)m->ctx.size()) return PT_ERR_INVALID;
+    if (!m || !m->have_cam || k < 0 || k >= (int)m->ctx.size() || m->strip > 0) return PT_ERR_INVALID;
     band(m->height, (int)m->ctx.size(), k, row_begin, row_end);
     return PT_OK;
 }
@@ -146,6 +200,7 @@ int pt_multi_download_image(pt_multi *m, float *host_rgb)
 {
     if (!m || !host_rgb || !m->have_cam) return PT_ERR_INVALID;
     const int n = (int)m->ctx.size();
+    if (m->strip > 0 && n > 1) return copy_strips(m, host_rgb, nullptr, 0, /*to_frame=*/true);
     for (int k = 0; k < n; ++k) {
         int r0, r1;
         band(m->height, n, k, &r0, &r1);
@@ -160,6 +215,7 @@ int pt_multi_upload_image(pt_multi *m, const float *host_rgb)
 {
     if (!m || !host_rgb || !m->have_cam) return PT_ERR_INVALID;
     const int n = (int)m->ctx.size();
+    if (m->strip > 0 && n > 1) return copy_strips(m, const_cast<float *>(host_rgb), nullptr, 0, /*to_frame=*/false);
     for (int k = 0; k < n; ++k) {
         int r0, r1;
         band(m->height, n, k, &r0, &r1);
@@ -177,6 +233,7 @@ int pt_multi_gather_to_device(pt_multi *m, void *device_rgb, int dst_device)
     const int n = (int)m->ctx.size();
     int rc = pt_multi_synchronize(m);
     if (rc != PT_OK) return rc;
+    if (m->strip > 0 && n > 1) return copy_strips(m, nullptr, device_rgb, dst_device, /*to_frame=*/true);
     std::vector<hipStream_t> streams((size_t)n, nullptr);
     for (int k = 0; k < n; ++k) {
         int r0, r1;

@@ -16,6 +16,8 @@
 //   PT_SEED (0)           RNG stream selector
 //   PT_DEVICES (0)        comma-separated HIP devices; with several, each renders a band of rows of the frame
 //                         (pt_multi_*), the bands are gathered into renderCam->image; PBO output then needs 1 device
+//   PT_STRIP_ROWS (8)     with several devices: rows per interleaved strip (device k renders strips k, k+n, ...); 0 = one
+//                         contiguous band per device
 //   PT_SHIM_BATCH (8)     iterations that may be pending inside the shim before they are rendered together
 //                         (only while nobody can observe them: no PBO, no read-back due); 1 = render every call
 //   PT_READBACK_EVERY (0) also copy the image back every N iterations (0 = only on the last one,
@@ -94,6 +96,7 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
         o.absorption = env_int("PT_ABSORPTION", o.absorption);
         o.seed = (unsigned)env_int("PT_SEED", 0);
         check(pt_multi_set_options(g.ctx, &o), "pt_set_options");
+        if (g.ndev > 1) check(pt_multi_set_strips(g.ctx, env_int("PT_STRIP_ROWS", 8)), "pt_multi_set_strips");
         g.readback_every = env_int("PT_READBACK_EVERY", 0);
         g.defer = env_int("PT_SHIM_BATCH", 8);
         if (g.defer < 1) g.defer = 1;

@@ -3,8 +3,9 @@
 The path shards trivially: one path per pixel per iteration, exclusive pixel ownership, RNG streams keyed on
 the GLOBAL pixel index, so any partition renders the same bits.  Each rank owns one
 contiguous band of rows -- a contiguous slice of the reference's row-major framebuffer
-(index = x + y*W, ref: src/raytraceKernel.cu:98) -- renders it with no communication, and the bands are
-gathered to rank 0 once, when the host wants the image.  The gather is the only exchange step; over xGMI
+(index = x + y*W, ref: src/raytraceKernel.cu:98) -- or, to balance the ranks when path lengths vary down the
+frame, interleaved strips of STRIP_ROWS rows (strip k belongs to rank k % world); renders them with
+no communication, and the tiles are gathered to rank 0 once, when the host wants the image.  The gather is the only exchange step; over xGMI
 every peer has its own direct link to the root, so it is a set of concurrent point-to-point sends
 (torch.distributed.gather on the nccl = RCCL backend), not a ring.
 """
@@ -19,6 +20,47 @@ def band_rows(height, world, rank):
 
 def max_band_rows(height, world):
     return max(band_rows(height, world, r)[1] - band_rows(height, world, r)[0] for r in range(world))
+
+
+STRIP_ROWS = 8     # stripH = 8
+
+
+def strip_local_rows(height, world, rank, strip_rows=STRIP_ROWS):
+    """Number of frame rows `rank` owns under interleaved strips (== pt_strip_local_rows of the C-ABI)."""
+    if world < 1 or not 0 <= rank < world or strip_rows < 1:
+        raise ValueError("rank/world/strip_rows")
+    nstrips = (height + strip_rows - 1) // strip_rows
+    return sum(min(strip_rows, height - k * strip_rows) for k in range(rank, nstrips, world))
+
+
+def strip_global_rows(height, world, rank, strip_rows=STRIP_ROWS):
+    """Frame rows of the rank's local rows 0, 1, ... (its strips packed in order)."""
+    nstrips = (height + strip_rows - 1) // strip_rows
+    rows = []
+    for k in range(rank, nstrips, world):
+        rows.extend(range(k * strip_rows, min(height, (k + 1) * strip_rows)))
+    return rows
+
+
+def max_strip_rows(height, world, strip_rows=STRIP_ROWS):
+    return max(strip_local_rows(height, world, r, strip_rows) for r in range(world))
+
+
+def gather_strips(local_tile, height, world, rank, strip_rows=STRIP_ROWS, dist=None, dst=0):
+    """Gather the per-rank strip tiles (tensors [max_strip_rows, W, 3], the first strip_local_rows rows valid) to
+    `dst` and put every row at its place in the [height, W, 3] frame.  Returns the frame on dst, None elsewhere."""
+    import torch
+    if world == 1:
+        return local_tile[:height]
+    bufs = [torch.empty_like(local_tile) for _ in range(world)] if rank == dst else None
+    dist.gather(local_tile, bufs, dst=dst)
+    if rank != dst:
+        return None
+    frame = torch.empty((height,) + tuple(local_tile.shape[1:]), dtype=local_tile.dtype, device=local_tile.device)
+    for r in range(world):
+        rows = torch.as_tensor(strip_global_rows(height, world, r, strip_rows), dtype=torch.long, device=local_tile.device)
+        frame.index_copy_(0, rows, bufs[r][: rows.numel()])
+    return frame
 
 
 def weak_scaled_frame(width, height, world):

@@ -546,3 +546,75 @@ def test_absorption_in_glass_matches_oracle(pkg):
     gpu2, lg2, st2 = gpu_render(pkg, "cornell_glass.txt", W, H, depth, iters=iters, rotat=1, absorption=1, direct_light=1, rr_start=1)
     check(gpu2, cpu2, lg2, [int(x) for x in lc2], "absorption + direct lighting + RR")
     assert int(st2.shadow_rays) == sh[0]
+
+
+# ---------------------------------------------------------------- interleaved-strip tiles
+@pytest.mark.parametrize("world,strip,h", [(2, 8, 90), (3, 8, 90), (4, 4, 37), (8, 8, 128), (3, 5, 16)])
+def test_strip_tiles_reassemble_to_full_frame(pkg, world, strip, h):
+    """pt_options.strip_*: strip k of `strip` rows belongs to rank k % world; every rank renders its strips packed.
+    RNG is keyed on the global pixel, so putting the rows back gives the single-context frame bit for bit -- including a
+    short last strip and direct lighting (which reads and writes per-pixel state by local index)."""
+    from project3_pathtracer_amd import sharding
+    W, depth = 72, 4
+    full, lf, _ = gpu_render(pkg, "sampleScene_spec.txt", W, h, depth, iters=3, direct_light=1)
+    frame = np.full_like(full, -1.0)
+    live = [0] * depth
+    for rank in range(world):
+        t, lt, _ = gpu_render(pkg, "sampleScene_spec.txt", W, h, depth, iters=3, direct_light=1, strip_rows=strip,
+                              strip_world=world, strip_rank=rank)
+        rows = sharding.strip_global_rows(h, world, rank, strip)
+        assert t.shape == (len(rows), W, 3) == (pkg.lib().pt_strip_local_rows(h, strip, world, rank), W, 3)
+        frame[rows] = t
+        live = [a + b for a, b in zip(live, lt)]
+    assert np.array_equal(frame, full) and live == lf
+
+
+def test_strip_options_are_validated(pkg):
+    with pkg.Renderer(0) as r:
+        for bad in (dict(strip_rows=8, strip_world=0), dict(strip_rows=8, strip_world=2, strip_rank=2),
+                    dict(strip_rows=8, strip_world=2, strip_rank=0, row_begin=0, row_end=4), dict(strip_rows=-1)):
+            with pytest.raises(pkg.PtError):
+                r.set_options(**bad)
+            r.set_options(strip_rows=0, strip_world=0, strip_rank=0, row_begin=0, row_end=0)
+
+
+@pytest.mark.parametrize("ndev,strip", [(2, 8), (3, 4)])
+def test_multi_device_handle_with_strips(pkg, ndev, strip):
+    """pt_multi_set_strips: the handle shards by interleaved strips; host download, host upload (resume) and the
+    device gather put every row at its place."""
+    import torch
+    L = pkg.lib()
+    W, H, depth, iters = 100, 53, 4, 2
+    sc = pkg.SceneFile(os.path.join(SCENES, "sampleScene_spec.txt"))
+    sc.set_resolution(W, H)
+    ref, lr, _ = gpu_render(pkg, "sampleScene_spec.txt", W, H, depth, iters=iters)
+    ref4, _, _ = gpu_render(pkg, "sampleScene_spec.txt", W, H, depth, iters=iters + 2)
+    devs = (C.c_int * ndev)(*([0] * ndev))
+    m = C.c_void_p()
+    assert L.pt_multi_create(devs, ndev, C.byref(m)) == 0
+    try:
+        o = pkg.Options()
+        L.pt_default_options(C.byref(o))
+        o.depth = depth
+        assert L.pt_multi_set_options(m, C.byref(o)) == 0
+        assert L.pt_multi_set_strips(m, strip) == 0
+        assert L.pt_multi_set_scene(m, sc.geoms, sc.n_objects, sc.mats, sc.n_materials) == 0
+        assert L.pt_multi_set_camera(m, C.byref(sc.camera)) == 0
+        assert L.pt_multi_clear_image(m) == 0
+        assert L.pt_multi_render(m, 1, iters) == 0
+        host = np.zeros((H, W, 3), dtype=np.float32)
+        assert L.pt_multi_download_image(m, host.ctypes.data) == 0
+        assert np.array_equal(host, ref)
+        dev = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+        assert L.pt_multi_gather_to_device(m, dev.data_ptr(), 0) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(dev.cpu().numpy(), ref)
+        st = pkg.Stats()
+        assert L.pt_multi_get_stats(m, C.byref(st)) == 0
+        assert [int(x) for x in st.live_in[:depth]] == lr
+        assert L.pt_multi_upload_image(m, host.ctypes.data) == 0
+        assert L.pt_multi_render(m, iters + 1, 2) == 0
+        assert L.pt_multi_download_image(m, host.ctypes.data) == 0
+        assert np.array_equal(host, ref4)
+    finally:
+        L.pt_multi_destroy(m)

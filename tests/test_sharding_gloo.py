@@ -56,6 +56,53 @@ def worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
+def strip_worker(rank, world, port, out_path, strip):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    load_package()
+    from project3_pathtracer_amd import sharding
+    rows = sharding.strip_global_rows(H, world, rank, strip)
+    tile = torch.zeros((sharding.max_strip_rows(H, world, strip), W, 3), dtype=torch.float32)
+    tile[: len(rows)] = torch.from_numpy(render_rows(0, H)[rows])
+    frame = sharding.gather_strips(tile, H, world, rank, strip, dist=dist, dst=0)
+    if rank == 0:
+        np.save(out_path, frame.numpy())
+    else:
+        assert frame is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,strip", [(2, 8), (3, 4)])
+def test_strips_gather_to_full_frame(world, strip, tmp_path):
+    """Interleaved strips (what bench.py uses for N > 1): strip k -> rank k % world, gathered rows land at their place."""
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(strip_worker, args=(world, free_port(), out, strip), nprocs=world, join=True)
+    assert np.array_equal(np.load(out), render_rows(0, H))
+
+
+def test_strip_partition_properties():
+    pkg = load_package()
+    from project3_pathtracer_amd import sharding
+    L = pkg.lib()
+    for h in (8, 54, 1080, 2160, 3054):
+        for world in (1, 2, 3, 4, 8):
+            for strip in (1, 8, 16):
+                if strip * world > h + strip - 1:
+                    continue
+                seen = []
+                for r in range(world):
+                    rows = sharding.strip_global_rows(h, world, r, strip)
+                    assert len(rows) == sharding.strip_local_rows(h, world, r, strip) == L.pt_strip_local_rows(h, strip, world, r)
+                    assert rows == [L.pt_strip_global_row(strip, world, r, k) for k in range(len(rows))]
+                    seen += rows
+                assert sorted(seen) == list(range(h))                      # every row owned exactly once
+                sizes = [sharding.strip_local_rows(h, world, r, strip) for r in range(world)]
+                assert max(sizes) - min(sizes) <= strip and sharding.max_strip_rows(h, world, strip) == max(sizes)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_bands_gather_to_full_frame(world, tmp_path):
     out = str(tmp_path / "frame.npy")
