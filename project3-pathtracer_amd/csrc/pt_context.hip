@@ -153,12 +153,45 @@ void build_bvh(const std::vector<Aabb> &boxes, std::vector<int> &idx, size_t lo,
     if (hi - lo == 1) {
         nodes[me].prim = idx[lo];
     } else {
-        int axis = 0;
-        for (int a = 1; a < 3; ++a) if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
-        const size_t mid = lo + (hi - lo) / 2;
-        std::nth_element(idx.begin() + (long)lo, idx.begin() + (long)mid, idx.begin() + (long)hi, [&](int x, int y) {
-            return boxes[(size_t)x].lo[axis] + boxes[(size_t)x].hi[axis] < boxes[(size_t)y].lo[axis] + boxes[(size_t)y].hi[axis];
-        });
+        // surface-area heuristic, full sweep: for every axis sort by centroid and take the split that minimises
+        // area(left)*count(left) + area(right)*count(right)  (the hierarchy only culls, so any split is correct)
+        const size_t n = hi - lo;
+        auto half_area = [](const Aabb &b) {
+            const double dx = (double)b.hi[0] - b.lo[0], dy = (double)b.hi[1] - b.lo[1], dz = (double)b.hi[2] - b.lo[2];
+            return dx * dy + dy * dz + dz * dx;
+        };
+        auto grow = [](Aabb &u2, const Aabb &b) {
+            for (int a = 0; a < 3; ++a) {
+                if (b.lo[a] < u2.lo[a]) u2.lo[a] = b.lo[a];
+                if (b.hi[a] > u2.hi[a]) u2.hi[a] = b.hi[a];
+            }
+        };
+        double best_cost = 1e300;
+        int best_axis = 0;
+        size_t best_left = n / 2;
+        std::vector<int> order(n), best_order;
+        std::vector<double> right_area(n);
+        for (int axis = 0; axis < 3; ++axis) {
+            if (!(cmax[axis] > cmin[axis])) continue;
+            std::copy(idx.begin() + (long)lo, idx.begin() + (long)hi, order.begin());
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+                return boxes[(size_t)x].lo[axis] + boxes[(size_t)x].hi[axis] < boxes[(size_t)y].lo[axis] + boxes[(size_t)y].hi[axis];
+            });
+            Aabb acc = boxes[(size_t)order[n - 1]];
+            for (size_t k = n - 1; k >= 1; --k) {                 // right_area[k] = area of order[k..n)
+                grow(acc, boxes[(size_t)order[k]]);
+                right_area[k] = half_area(acc);
+            }
+            acc = boxes[(size_t)order[0]];
+            for (size_t k = 1; k < n; ++k) {                      // split: left = order[0..k), right = order[k..n)
+                grow(acc, boxes[(size_t)order[k - 1]]);
+                const double cost = half_area(acc) * (double)k + right_area[k] * (double)(n - k);
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_left = k; best_order = order; }
+            }
+        }
+        (void)best_axis;
+        if (!best_order.empty()) std::copy(best_order.begin(), best_order.end(), idx.begin() + (long)lo);
+        const size_t mid = lo + best_left;
         nodes[me].prim = -1;
         build_bvh(boxes, idx, lo, mid, nodes);
         build_bvh(boxes, idx, mid, hi, nodes);

@@ -147,18 +147,23 @@ __device__ __forceinline__ Hit nearestHitBvh(const KParams &p, const Prim *s_pri
     const float iz = __builtin_amdgcn_rcpf(fabsf(d.z) > 1e-20f ? d.z : (d.z < 0 ? -1e-20f : 1e-20f));
     // primitives that span most of the scene (walls, big lights) would bloat every box above them: they are kept
     // out of the hierarchy and tested by every ray, wave-uniformly through the scalar unit
+    // the normal is only needed for the final winner: candidates keep (distance, primitive, point, box face)
+    uint32_t best_face = 0u;
     for (int k = 0; k < p.nbig; ++k) {
         const int g = p.big[k];
         const Prim P = load_prim_scalar(p.prims, g);
-        f3 ip, in;
-        const float t = intersectPrim<FIRST>(P, o, d, FIRST ? load_ro_eye(p.ro_eye, g) : o, ip, in);
+        f3 ro = FIRST ? load_ro_eye(p.ro_eye, g) : o, rd;
+        float tc;
+        uint32_t face;
+        if (!candidateT<FIRST>(P.type, P.inv, o, d, ro, rd, tc, face)) continue;
+        f3 ip;
+        const float t = hitPoint(P.fwd, o, ro, rd, tc, ip);
         if (t > 0 && (!h.any || t < best_t || (t == best_t && (uint32_t)g < best_g))) {
             h.any = true;
             best_t = t;
             best_g = (uint32_t)g;
+            best_face = face;
             h.p = ip;
-            h.n = in;
-            h.material = P.material;
         }
     }
     uint32_t i = 0;
@@ -188,17 +193,26 @@ __device__ __forceinline__ Hit nearestHitBvh(const KParams &p, const Prim *s_pri
         }
         if (prim < 0) break;
         if (DEBUG_BVH) dbg_leaves++;
-        const Prim &P = s_prims[prim];                     // per-lane gather from the LDS copy
-        f3 ip, in;
-        const float t = intersectPrim<false>(P, o, d, o, ip, in);
+        const Prim &P = s_prims[prim];                     // per-lane gather of the record (L1/L2)
+        f3 ro = o, rd;
+        float tc;
+        uint32_t face;
+        if (!candidateT<false>(P.type, P.inv, o, d, ro, rd, tc, face)) continue;
+        f3 ip;
+        const float t = hitPoint(P.fwd, o, ro, rd, tc, ip);
         if (t > 0 && (!h.any || t < best_t || (t == best_t && (uint32_t)prim < best_g))) {
             h.any = true;
             best_t = t;
             best_g = (uint32_t)prim;
+            best_face = face;
             h.p = ip;
-            h.n = in;
-            h.material = P.material;
         }
+    }
+    if (h.any) {
+        const Prim &P = s_prims[best_g];
+        h.material = P.material;
+        if (P.type == 0u) h.n = sphereNormal(h.p, mk(P.cx, P.cy, P.cz));
+        else h.n = boxNormal(P.fwd, best_face);
     }
     if (DEBUG_BVH) {
         // per ray: nodes, leaves; per wave: the longest lane (what the wave pays)
