@@ -68,6 +68,7 @@ struct pt_ctx {
     ptd::Prim *d_prims = nullptr;
     float *d_mats = nullptr;
     float *d_ro_eye = nullptr;
+    float *d_box_eye = nullptr;
     int *d_lights = nullptr;    // direct lighting: indices of the emissive primitives
     ptd::BvhNode *d_bvh = nullptr;
     float *d_image_own = nullptr;
@@ -358,6 +359,23 @@ int configure(pt_ctx *c)
         HIP_TRY(hipMalloc((void **)&c->d_ro_eye, ro.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(c->d_ro_eye, ro.data(), ro.size() * sizeof(float), hipMemcpyHostToDevice));
 
+        // ... and a wave of camera rays covers a small solid angle: the padded world box of every primitive,
+        // relative to the eye, lets a wave skip the primitives none of its rays can reach (culling only)
+        std::vector<float> be(prims.size() * 8, 0.0f);
+        for (size_t i = 0; i < c->geoms.size(); ++i) {
+            const Aabb b = prim_bounds(c->geoms[i]);
+            const double e[3] = {c->cam.position.x, c->cam.position.y, c->cam.position.z};
+            for (int a = 0; a < 3; ++a) {
+                const double lo = (double)b.lo[a] - e[a], hi = (double)b.hi[a] - e[a];
+                const double pad = 1e-6 * (fabs(lo) + fabs(hi) + fabs(e[a])) + 1e-6;      // fp32 rounding of the subtraction
+                be[8 * i + (size_t)a] = (float)(lo - pad);
+                be[8 * i + 4 + (size_t)a] = (float)(hi + pad);
+            }
+        }
+        if (c->d_box_eye) { (void)hipFree(c->d_box_eye); c->d_box_eye = nullptr; }
+        HIP_TRY(hipMalloc((void **)&c->d_box_eye, be.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(c->d_box_eye, be.data(), be.size() * sizeof(float), hipMemcpyHostToDevice));
+
         const size_t nM = c->mats.size();
         std::vector<float> planes((nM ? nM : 1) * ptd::M_PLANES, 0.0f);
         for (size_t i = 0; i < nM; ++i) {
@@ -376,6 +394,7 @@ int configure(pt_ctx *c)
     }
     k.prims = c->d_prims;
     k.ro_eye = c->d_ro_eye;
+    k.box_eye = getenv("PT_NO_EYE_CULL") ? nullptr : c->d_box_eye;
 
     // culling hierarchy (used by geom_path 4 / large scenes); MESH primitives have no geometry and stay out
     {
@@ -607,6 +626,7 @@ void pt_destroy(pt_ctx *c)
     if (c->d_prims) (void)hipFree(c->d_prims);
     if (c->d_mats) (void)hipFree(c->d_mats);
     if (c->d_ro_eye) (void)hipFree(c->d_ro_eye);
+    if (c->d_box_eye) (void)hipFree(c->d_box_eye);
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_bvh) (void)hipFree(c->d_bvh);
     if (c->d_image_own) (void)hipFree(c->d_image_own);

@@ -58,6 +58,7 @@ struct KParams {
     int nbig;              // primitives too large to cull (walls...): tested by every ray before the walk
     int big[16];           // their indices
     const float *ro_eye;   // per primitive: inverseTransform*(eye,1) as float4 (camera rays share their origin)
+    const float *box_eye;  // per primitive: padded world box minus the eye, (lo.xyz,0)(hi.xyz,0): wave cull of camera rays
     const float *mats;     // M_PLANES planes of nM floats
     float *image;          // tile framebuffer, fp32 RGB packed (12 B/pixel)
     int cull;              // 1 = skip primitives whose bounding sphere no lane of the wave can hit (large scenes)

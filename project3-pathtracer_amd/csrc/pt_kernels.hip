@@ -89,6 +89,26 @@ __device__ __forceinline__ f3 load_ro_eye(const float *ro_eye, int g)
     return mk(__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]));
 }
 
+// Camera rays only (they share the eye as origin): true when no ray of the wave can reach primitive g, judged by
+// its padded world box relative to the eye (host-side, KParams::box_eye).  It only ever skips primitives the exact
+// test would miss for every lane.  inv = approximate, finite reciprocal of the ray direction.
+__device__ __forceinline__ bool waveMissesBoxFromEye(const float *box_eye, int g, f3 inv, bool valid)
+{
+    const_u32_ptr q = (const_u32_ptr)(uintptr_t)(box_eye + 8 * g);
+    const float x0 = __uint_as_float(q[0]) * inv.x, x1 = __uint_as_float(q[4]) * inv.x;
+    const float y0 = __uint_as_float(q[1]) * inv.y, y1 = __uint_as_float(q[5]) * inv.y;
+    const float z0 = __uint_as_float(q[2]) * inv.z, z1 = __uint_as_float(q[6]) * inv.z;
+    const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+    const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    return __ballot(valid && tn <= tf) == 0ull;
+}
+__device__ __forceinline__ f3 approxInverse(f3 d)
+{
+    return mk(__builtin_amdgcn_rcpf(fabsf(d.x) > 1e-20f ? d.x : (d.x < 0 ? -1e-20f : 1e-20f)),
+              __builtin_amdgcn_rcpf(fabsf(d.y) > 1e-20f ? d.y : (d.y < 0 ? -1e-20f : 1e-20f)),
+              __builtin_amdgcn_rcpf(fabsf(d.z) > 1e-20f ? d.z : (d.z < 0 ? -1e-20f : 1e-20f)));
+}
+
 template <int GEOM, bool FIRST>
 __device__ __forceinline__ Hit nearestHitDirect(const KParams &p, const Prim *s_prims, f3 o, f3 d)
 {
@@ -261,8 +281,10 @@ __device__ __forceinline__ Hit nearestHitQueued(const KParams &p, const Prim *s_
     q.org[lane] = make_float4(o.x, o.y, o.z, 0.0f);
     wave_lds_fence();
     uint32_t qhead = 0, qtail = 0;                       // wave-uniform
+    const bool eye_cull = FIRST && p.box_eye != nullptr;
+    const f3 dinv = eye_cull ? approxInverse(d) : mk(0, 0, 0);
     for (int g = 0; g <= p.nG; ++g) {
-        if (g < p.nG) {
+        if (g < p.nG && !(eye_cull && waveMissesBoxFromEye(p.box_eye, g, dinv, valid))) {
             // candidate test: wave-uniform primitive (type + inverse transform through the scalar unit)
             const_u32_ptr hp = (const_u32_ptr)(uintptr_t)(p.prims + g);
             const uint32_t type = hp[0];
