@@ -69,6 +69,7 @@ struct pt_ctx {
     float *d_mats = nullptr;
     float *d_ro_eye = nullptr;
     float *d_box_eye = nullptr;
+    float *d_box_world = nullptr;
     int *d_lights = nullptr;    // direct lighting: indices of the emissive primitives
     ptd::BvhNode *d_bvh = nullptr;
     float *d_image_own = nullptr;
@@ -361,9 +362,10 @@ int configure(pt_ctx *c)
 
         // ... and a wave of camera rays covers a small solid angle: the padded world box of every primitive,
         // relative to the eye, lets a wave skip the primitives none of its rays can reach (culling only)
-        std::vector<float> be(prims.size() * 8, 0.0f);
+        std::vector<float> be(prims.size() * 8, 0.0f), bw(prims.size() * 8, 0.0f);
         for (size_t i = 0; i < c->geoms.size(); ++i) {
             const Aabb b = prim_bounds(c->geoms[i]);
+            for (int a = 0; a < 3; ++a) { bw[8 * i + (size_t)a] = b.lo[a]; bw[8 * i + 4 + (size_t)a] = b.hi[a]; }
             const double e[3] = {c->cam.position.x, c->cam.position.y, c->cam.position.z};
             for (int a = 0; a < 3; ++a) {
                 const double lo = (double)b.lo[a] - e[a], hi = (double)b.hi[a] - e[a];
@@ -375,6 +377,9 @@ int configure(pt_ctx *c)
         if (c->d_box_eye) { (void)hipFree(c->d_box_eye); c->d_box_eye = nullptr; }
         HIP_TRY(hipMalloc((void **)&c->d_box_eye, be.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(c->d_box_eye, be.data(), be.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (c->d_box_world) { (void)hipFree(c->d_box_world); c->d_box_world = nullptr; }
+        HIP_TRY(hipMalloc((void **)&c->d_box_world, bw.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(c->d_box_world, bw.data(), bw.size() * sizeof(float), hipMemcpyHostToDevice));
 
         const size_t nM = c->mats.size();
         std::vector<float> planes((nM ? nM : 1) * ptd::M_PLANES, 0.0f);
@@ -394,7 +399,9 @@ int configure(pt_ctx *c)
     }
     k.prims = c->d_prims;
     k.ro_eye = c->d_ro_eye;
-    k.box_eye = getenv("PT_NO_EYE_CULL") ? nullptr : c->d_box_eye;
+    k.box_eye = c->d_box_eye;
+    k.eye_cull = getenv("PT_NO_EYE_CULL") ? 0 : 1;
+    k.box_world = c->d_box_world;
 
     // culling hierarchy (used by geom_path 4 / large scenes); MESH primitives have no geometry and stay out
     {
@@ -627,6 +634,7 @@ void pt_destroy(pt_ctx *c)
     if (c->d_mats) (void)hipFree(c->d_mats);
     if (c->d_ro_eye) (void)hipFree(c->d_ro_eye);
     if (c->d_box_eye) (void)hipFree(c->d_box_eye);
+    if (c->d_box_world) (void)hipFree(c->d_box_world);
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_bvh) (void)hipFree(c->d_bvh);
     if (c->d_image_own) (void)hipFree(c->d_image_own);
@@ -644,7 +652,7 @@ int pt_set_options(pt_ctx *c, const pt_options *o)
     const int wg = o->workgroup;
     if (!(wg == 0 || wg == 64 || wg == 128 || wg == 256 || wg == 512 || wg == 1024))
         return fail(PT_ERR_INVALID, "workgroup %d not one of 0,64,128,256,512,1024", wg);
-    if (o->geom_path < 0 || o->geom_path > 4) return fail(PT_ERR_INVALID, "geom_path %d not in 0..4", o->geom_path);
+    if (o->geom_path < 0 || o->geom_path > 5) return fail(PT_ERR_INVALID, "geom_path %d not in 0..5", o->geom_path);
     if (o->row_begin < 0 || o->row_end < o->row_begin) return fail(PT_ERR_INVALID, "tile rows [%d,%d)", o->row_begin, o->row_end);
     if (o->strip_rows < 0 || (o->strip_rows > 0 && (o->strip_world < 1 || o->strip_rank < 0 || o->strip_rank >= o->strip_world)))
         return fail(PT_ERR_INVALID, "strips: rows %d, rank %d of %d", o->strip_rows, o->strip_rank, o->strip_world);

@@ -58,6 +58,8 @@ struct KParams {
     int nbig;              // primitives too large to cull (walls...): tested by every ray before the walk
     int big[16];           // their indices
     const float *ro_eye;   // per primitive: inverseTransform*(eye,1) as float4 (camera rays share their origin)
+    int eye_cull;          // 1 = camera-ray waves skip primitives outside their boxes (box_eye), ablation switch
+    const float *box_world; // per primitive: padded world box (lo.xyz,0)(hi.xyz,0): per-lane pre-test of the pair queue
     const float *box_eye;  // per primitive: padded world box minus the eye, (lo.xyz,0)(hi.xyz,0): wave cull of camera rays
     const float *mats;     // M_PLANES planes of nM floats
     float *image;          // tile framebuffer, fp32 RGB packed (12 B/pixel)
@@ -81,7 +83,7 @@ struct KParams {
 struct LaunchCfg {
     int workgroup;   // 64..1024
     int grid;        // workgroups per bounce launch
-    int geom;        // 0 scalar direct, 1 LDS direct, 2 hit queue, 3 per-lane hierarchy walk (pt_kernels.hip)
+    int geom;        // 0 scalar direct, 1 LDS direct, 2 hit queue, 3 per-lane hierarchy walk, 4 pair queue (pt_kernels.hip)
     int compact;     // 0 off, 1 per-wave sharded reservation, 2 workgroup scan + single counter
     int nee;         // 1 = explicit light sampling at diffuse vertices (compact must be 1)
 };

@@ -64,7 +64,12 @@ struct Hit {
 //                      (LDS-resident, depth-first with skip links, no stack) and runs the exact test only on the
 //                      leaves its ray can reach; per-lane primitive records are gathered from the LDS copy.  The
 //                      boxes are padded and only ever cull, so the nearest hit (ties -> lowest index) is unchanged.
-enum { GEOM_SCALAR = 0, GEOM_LDS = 1, GEOM_QUEUE = 2, GEOM_BVH = 3 };
+//   4  pair queue:     the uniform loop only runs a cheap per-lane test of the ray against the primitive's padded world
+//                      box and queues the (ray, primitive) pairs that pass -- spheres and boxes apart; the candidate test
+//                      itself AND the hit work then run on full 64-pair batches, each lane on its own pair (ray from
+//                      the owner's LDS slot, primitive record gathered from the LDS copy), results through the same
+//                      64-bit LDS atomic min.  The box test only ever drops pairs the exact test would miss.
+enum { GEOM_SCALAR = 0, GEOM_LDS = 1, GEOM_QUEUE = 2, GEOM_BVH = 3, GEOM_PAIR = 4 };
 
 // Conservative cull for large primitive lists: true when NO lane of the wave can hit the primitive, judged by a
 // padded world-space bounding sphere (centre = transform*(0,0,0,1), radius^2 in the record).  It only ever skips
@@ -281,7 +286,7 @@ __device__ __forceinline__ Hit nearestHitQueued(const KParams &p, const Prim *s_
     q.org[lane] = make_float4(o.x, o.y, o.z, 0.0f);
     wave_lds_fence();
     uint32_t qhead = 0, qtail = 0;                       // wave-uniform
-    const bool eye_cull = FIRST && p.box_eye != nullptr;
+    const bool eye_cull = FIRST && p.eye_cull != 0;
     const f3 dinv = eye_cull ? approxInverse(d) : mk(0, 0, 0);
     for (int g = 0; g <= p.nG; ++g) {
         if (g < p.nG && !(eye_cull && waveMissesBoxFromEye(p.box_eye, g, dinv, valid))) {
@@ -372,6 +377,128 @@ __device__ __forceinline__ Hit nearestHitQueued(const KParams &p, const Prim *s_
     return h;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// GEOM_PAIR
+// ---------------------------------------------------------------------------------------------------------------
+struct PairQueue {
+    uint32_t *q[2];               // [QCAP] pending pairs, lane | prim << 8: [0] spheres, [1] boxes
+    unsigned long long *key;      // [64] per owner lane: min over hits of (distance bits << 32 | prim << 8)
+    float4 *best;                 // [64] per owner lane: (hit point xyz, meta) of the current minimum
+    float4 *org, *dir;            // [64] per owner lane: the ray
+};
+static constexpr uint32_t PAIR_QUEUE_BYTES = 2 * QCAP * 4 + 64 * 8 + 3 * 64 * 16;
+static_assert(PAIR_QUEUE_BYTES <= WAVE_QUEUE_BYTES, "the pair queue lives in the hit queue's LDS region");
+
+// one batch: lane l takes pair head + l of queue TYPE (0 sphere, 1 box), whoever owns it
+template <uint32_t TYPE>
+__device__ __forceinline__ void pairBatch(const Prim *s_prims, const PairQueue &q, uint32_t head, uint32_t nb, uint32_t lane)
+{
+    wave_lds_fence();
+    unsigned long long mykey = KEY_NONE;
+    uint32_t owner = 0u;
+    float4 mine = make_float4(0, 0, 0, 0);
+    if (lane < nb) {
+        const uint32_t e = q.q[TYPE][(head + lane) & (QCAP - 1u)];
+        owner = e & 63u;
+        const uint32_t prim = e >> 8;
+        const float4 oo = q.org[owner], dd = q.dir[owner];
+        const f3 o = mk(oo.x, oo.y, oo.z), d = mk(dd.x, dd.y, dd.z);
+        const float4 *iv = reinterpret_cast<const float4 *>(s_prims[prim].inv);
+        const float4 i0 = iv[0], i1 = iv[1], i2 = iv[2];
+        const float inv[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
+        f3 ro = o, rd;
+        float t;
+        uint32_t face;
+        if (candidateT<false>(TYPE, inv, o, d, ro, rd, t, face)) {
+            const float4 f0 = iv[3], f1 = iv[4], f2 = iv[5];          // fwd rows follow the inverse rows
+            const float fwd[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
+            f3 real;
+            const float dist = hitPoint(fwd, o, ro, rd, t, real);
+            if (dist > 0) {                                  // same admission test as the direct path: t > 0
+                mykey = ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned long long)(prim << 8);
+                mine = make_float4(real.x, real.y, real.z, __uint_as_float((prim << 8) | (face << 28)));
+                __hip_atomic_fetch_min(&q.key[owner], mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+    }
+    wave_lds_fence();
+    if (mykey != KEY_NONE && q.key[owner] == mykey) q.best[owner] = mine;   // unique writer: keys are unique
+    wave_lds_fence();
+}
+
+// Must be entered by all 64 lanes of the wave (lanes without a ray pass valid = false).
+template <bool FIRST>
+__device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const Prim *s_prims, const PairQueue q, f3 o, f3 d, bool valid,
+                                               uint32_t lane)
+{
+    q.key[lane] = KEY_NONE;
+    q.org[lane] = make_float4(o.x, o.y, o.z, 0.0f);
+    q.dir[lane] = make_float4(d.x, d.y, d.z, 0.0f);
+    uint32_t head[2] = {0u, 0u}, tail[2] = {0u, 0u};        // wave-uniform
+    const f3 dinv = approxInverse(d);
+    for (int g = 0; g < p.nG; ++g) {
+        const_u32_ptr hp = (const_u32_ptr)(uintptr_t)(p.prims + g);
+        const uint32_t type = hp[0];
+        if (type > 1u) continue;                             // MESH: never has geometry
+        // padded world box of the primitive against this lane's ray (camera rays: box relative to the shared eye)
+        const_u32_ptr bq = (const_u32_ptr)(uintptr_t)((FIRST ? p.box_eye : p.box_world) + 8 * g);
+        const f3 lo = mk(__uint_as_float(bq[0]), __uint_as_float(bq[1]), __uint_as_float(bq[2]));
+        const f3 hi = mk(__uint_as_float(bq[4]), __uint_as_float(bq[5]), __uint_as_float(bq[6]));
+        const f3 a = FIRST ? lo : lo - o, b = FIRST ? hi : hi - o;
+        const float x0 = a.x * dinv.x, x1 = b.x * dinv.x;
+        const float y0 = a.y * dinv.y, y1 = b.y * dinv.y;
+        const float z0 = a.z * dinv.z, z1 = b.z * dinv.z;
+        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        const bool pass = valid && tn <= tf;
+        const uint64_t mask = __ballot(pass);
+        if (mask == 0ull) continue;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (type == 0u) {                                    // wave-uniform
+            if (pass) q.q[0][(tail[0] + rank) & (QCAP - 1u)] = lane | ((uint32_t)g << 8);
+            tail[0] += (uint32_t)__popcll(mask);
+            if (tail[0] - head[0] >= 64u) { pairBatch<0u>(s_prims, q, head[0], 64u, lane); head[0] += 64u; }
+        } else {
+            if (pass) q.q[1][(tail[1] + rank) & (QCAP - 1u)] = lane | ((uint32_t)g << 8);
+            tail[1] += (uint32_t)__popcll(mask);
+            if (tail[1] - head[1] >= 64u) { pairBatch<1u>(s_prims, q, head[1], 64u, lane); head[1] += 64u; }
+        }
+    }
+    if (tail[0] != head[0]) pairBatch<0u>(s_prims, q, head[0], tail[0] - head[0], lane);
+    if (tail[1] != head[1]) pairBatch<1u>(s_prims, q, head[1], tail[1] - head[1], lane);
+    wave_lds_fence();
+    Hit h;
+    h.any = false;
+    h.material = 0;
+    h.prim = 0;
+    h.t = 0.0f;
+    h.p = mk(0, 0, 0);
+    h.n = mk(0, 0, 0);
+    const unsigned long long k = q.key[lane];
+    if (valid && k != KEY_NONE) {
+        const float4 b = q.best[lane];
+        const uint32_t meta = __float_as_uint(b.w);
+        const uint32_t prim = (meta >> 8) & 0xFFFFFu;
+        const uint32_t face = meta >> 28;
+        const Prim &P = s_prims[prim];                       // per-lane gather from the LDS copy
+        h.any = true;
+        h.prim = prim;
+        h.t = __uint_as_float((uint32_t)(k >> 32));
+        h.p = mk(b.x, b.y, b.z);
+        h.material = P.material;
+        if (P.type == 0u) {
+            const float4 c = *reinterpret_cast<const float4 *>(&P.cx);
+            h.n = sphereNormal(h.p, mk(c.x, c.y, c.z));
+        } else {
+            const float4 *fw = reinterpret_cast<const float4 *>(P.fwd);
+            const float4 f0 = fw[0], f1 = fw[1], f2 = fw[2];
+            const float fwd[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
+            h.n = boxNormal(fwd, face);
+        }
+    }
+    return h;
+}
+
 // nearest hit of (o, d) for the lanes with want == true, by the GEOM path.  Every lane of the wave must make the call
 // (the hit queue uses all 64 lanes as workers whatever their own ray).
 template <int GEOM, bool FIRST>
@@ -379,6 +506,17 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const Prim *s_prims,
                                           f3 o, f3 d, bool want, uint32_t lane)
 {
     if (GEOM == GEOM_QUEUE) return nearestHitQueued<FIRST>(p, s_prims, wq, o, d, want, lane);
+    if (GEOM == GEOM_PAIR) {
+        PairQueue pq;
+        unsigned char *b = reinterpret_cast<unsigned char *>(wq.rec);         // same LDS region as the hit queue
+        pq.q[0] = reinterpret_cast<uint32_t *>(b);
+        pq.q[1] = reinterpret_cast<uint32_t *>(b + QCAP * 4);
+        pq.key = reinterpret_cast<unsigned long long *>(b + 2 * QCAP * 4);
+        pq.best = reinterpret_cast<float4 *>(b + 2 * QCAP * 4 + 64 * 8);
+        pq.org = reinterpret_cast<float4 *>(b + 2 * QCAP * 4 + 64 * 8 + 64 * 16);
+        pq.dir = reinterpret_cast<float4 *>(b + 2 * QCAP * 4 + 64 * 8 + 2 * 64 * 16);
+        return nearestHitPairs<FIRST>(p, s_prims, pq, o, d, want, lane);
+    }
     Hit h;
     h.any = false;
     h.material = 0;
@@ -412,7 +550,7 @@ template <int WG, bool FIRST, int GEOM, int COMPACT, bool NEE = false>
 __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce)
 {
     constexpr int NW = WG / 64;
-    constexpr bool PRIMS_IN_LDS = (GEOM == GEOM_LDS || GEOM == GEOM_QUEUE);   // GEOM_BVH gathers records from global memory (L1/L2)
+    constexpr bool PRIMS_IN_LDS = (GEOM == GEOM_LDS || GEOM == GEOM_QUEUE || GEOM == GEOM_PAIR);   // GEOM_BVH gathers records from global memory (L1/L2)
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     // LDS carve: [prims nG*128 B (GEOM 1,2)] [per-wave hit queues (GEOM 2)] [material planes] [scan scratch]
     Prim *s_prims = reinterpret_cast<Prim *>(smem);
@@ -420,7 +558,7 @@ __global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce
     const float4 *s_nodes = reinterpret_cast<const float4 *>(smem + prim_bytes);
     const int node_bytes = (GEOM == GEOM_BVH) ? p.nnodes * (int)sizeof(BvhNode) : 0;
     unsigned char *s_queue = smem + prim_bytes + node_bytes;
-    const int queue_bytes = (GEOM == GEOM_QUEUE) ? NW * (int)WAVE_QUEUE_BYTES : 0;
+    const int queue_bytes = (GEOM == GEOM_QUEUE || GEOM == GEOM_PAIR) ? NW * (int)WAVE_QUEUE_BYTES : 0;
     float *s_mats = reinterpret_cast<float *>(s_queue + queue_bytes);
     const int mat_words = (p.nM * M_PLANES + 3) & ~3;
     uint32_t *s_scan = reinterpret_cast<uint32_t *>(s_mats + mat_words);   // [2][NW] wave totals, [2] bases
@@ -939,8 +1077,8 @@ __global__ __launch_bounds__(256) void k_send_image_to_pbo(pt_uchar4 *pbo, const
 // ---------------------------------------------------------------------------------------------
 size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg)
 {
-    size_t prim = (cfg.geom == GEOM_LDS || cfg.geom == GEOM_QUEUE) ? (size_t)p.nG * sizeof(Prim) : 0;
-    size_t queue = cfg.geom == GEOM_QUEUE ? (size_t)(cfg.workgroup / 64) * WAVE_QUEUE_BYTES : 0;
+    size_t prim = (cfg.geom == GEOM_LDS || cfg.geom == GEOM_QUEUE || cfg.geom == GEOM_PAIR) ? (size_t)p.nG * sizeof(Prim) : 0;
+    size_t queue = (cfg.geom == GEOM_QUEUE || cfg.geom == GEOM_PAIR) ? (size_t)(cfg.workgroup / 64) * WAVE_QUEUE_BYTES : 0;
     if (cfg.geom == GEOM_BVH) prim += (size_t)p.nnodes * sizeof(BvhNode);
     size_t mats = (size_t)((p.nM * M_PLANES + 3) & ~3) * sizeof(float);
     size_t scan = (size_t)(2 * (cfg.workgroup / 64) + 2) * sizeof(uint32_t);
@@ -969,6 +1107,7 @@ static const void *bounce_fn_geom(bool first, int compact, int nee)
 template <int WG>
 static const void *bounce_fn_wg(bool first, int geom, int compact, int nee)
 {
+    if (geom == GEOM_PAIR) return bounce_fn_geom<WG, GEOM_PAIR>(first, compact, nee);
     if (geom == GEOM_BVH) return bounce_fn_geom<WG, GEOM_BVH>(first, compact, nee);
     if (geom == GEOM_QUEUE) return bounce_fn_geom<WG, GEOM_QUEUE>(first, compact, nee);
     if (geom == GEOM_LDS) return bounce_fn_geom<WG, GEOM_LDS>(first, compact, nee);
