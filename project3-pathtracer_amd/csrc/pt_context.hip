@@ -121,14 +121,14 @@ struct Aabb { float lo[3], hi[3]; };
 // Padded world-space box of one primitive: |x_a - c_a| <= 0.5 * sum_i |M[a][i]| for the unit cube and
 // <= 0.5 * sqrt(sum_i M[a][i]^2) for the r = .5 sphere (M = rows 0..2 of the transform); +1 % and +1e-3 absorb the
 // fp32 rounding of the traversal's slab test and the 1e-4 back-off of getPointOnRay.
-Aabb prim_bounds(const pt_static_geom &g)
+Aabb prim_bounds(const pt_static_geom &g, double rel = 1.01, double abs_pad = 1e-3)
 {
     const float *rows[3] = {&g.transform.x.x, &g.transform.y.x, &g.transform.z.x};
     Aabb b;
     for (int a = 0; a < 3; ++a) {
         const double m0 = rows[a][0], m1 = rows[a][1], m2 = rows[a][2], c = rows[a][3];
         double h = (g.type == PT_SPHERE) ? 0.5 * sqrt(m0 * m0 + m1 * m1 + m2 * m2) : 0.5 * (fabs(m0) + fabs(m1) + fabs(m2));
-        h = h * 1.01 + 1e-3 + 1e-6 * fabs(c);
+        h = h * rel + abs_pad + 1e-6 * fabs(c);
         b.lo[a] = (float)(c - h);
         b.hi[a] = (float)(c + h);
     }
@@ -364,7 +364,9 @@ int configure(pt_ctx *c)
         // relative to the eye, lets a wave skip the primitives none of its rays can reach (culling only)
         std::vector<float> be(prims.size() * 8, 0.0f), bw(prims.size() * 8, 0.0f);
         for (size_t i = 0; i < c->geoms.size(); ++i) {
-            const Aabb b = prim_bounds(c->geoms[i]);
+            // hit-or-miss culling only (no distance pruning): the padding just has to cover fp32 rounding (1e-6 of the
+            // coordinates), and a tight one keeps a ray that leaves a wall (0.0002 above it) outside that wall's box
+            const Aabb b = prim_bounds(c->geoms[i], 1.005, 1e-4);
             for (int a = 0; a < 3; ++a) { bw[8 * i + (size_t)a] = b.lo[a]; bw[8 * i + 4 + (size_t)a] = b.hi[a]; }
             const double e[3] = {c->cam.position.x, c->cam.position.y, c->cam.position.z};
             for (int a = 0; a < 3; ++a) {
@@ -460,7 +462,7 @@ int configure(pt_ctx *c)
     pt::LaunchCfg &cfg = c->cfg;
     cfg.workgroup = o.workgroup ? o.workgroup : 256;
     // library choice: the hit queue pays when most primitives are hit by some lane of every wave (small scenes)
-    cfg.geom = o.geom_path == 0 ? (k.nG <= 32 ? 2 : 3) : o.geom_path - 1;
+    cfg.geom = o.geom_path == 0 ? (k.nG <= 32 ? 4 : 3) : o.geom_path - 1;
     cfg.compact = o.compaction;
     cfg.nee = k.nlights > 0 ? 1 : 0;             // no lights: nothing to sample, the plain kernels are exact
     k.cull = (k.nG > 32 && !getenv("PT_NO_CULL")) ? 1 : 0;
@@ -941,6 +943,9 @@ int pt_get_stats(pt_ctx *c, pt_stats *out)
                 (double)h.clk[0] / (double)h.clk[1] * 100.0);
     out->bounce_launches = c->bounce_launches;
     out->shadow_rays = h.shadow_rays;
+    if (getenv("PT_DEBUG_PAIR") && h.dbg[4])
+        fprintf(stderr, "[ptamd] pair queue: per ray %.2f sphere + %.2f box pairs; candidates that hit: %.2f + %.2f per ray; batches per wave round %.2f\n",
+                (double)h.dbg[0] / h.dbg[4], (double)h.dbg[1] / h.dbg[4], (double)h.dbg[2] / h.dbg[4], (double)h.dbg[3] / h.dbg[4], (double)h.dbg[5] / h.dbg[6]);
     if (getenv("PT_DEBUG_CLOCK") && h.dbg[2])
         fprintf(stderr, "[ptamd] hierarchy walk: %.1f nodes, %.2f leaves per ray; per wave (longest lane): %.1f nodes, %.2f leaves, %.2f rounds\n",
                 (double)h.dbg[0] / (double)h.dbg[2], (double)h.dbg[1] / (double)h.dbg[2], (double)h.dbg[3] / (double)h.dbg[6],

@@ -25,6 +25,7 @@ using namespace ptd;
 
 static constexpr uint32_t DEAD = 0xFFFFFFFFu;
 static constexpr bool DEBUG_CULL = false;
+static constexpr bool DEBUG_PAIR = false;
 static constexpr bool DEBUG_BVH = false;         // count node / leaf visits of the hierarchy walk into IterState::dbg
 static constexpr int MAXSLOT = 8;                 // iterations in flight per launch sequence (pt_internal.h PT_MAX_BATCH)
 static constexpr uint32_t SLOT_SHIFT = 28;        // pixel word = tile-local pixel | slot << 28
@@ -385,20 +386,25 @@ struct PairQueue {
     unsigned long long *key;      // [64] per owner lane: min over hits of (distance bits << 32 | prim << 8)
     float4 *best;                 // [64] per owner lane: (hit point xyz, meta) of the current minimum
     float4 *org, *dir;            // [64] per owner lane: the ray
+    unsigned long long *dbg;
 };
 static constexpr uint32_t PAIR_QUEUE_BYTES = 2 * QCAP * 4 + 64 * 8 + 3 * 64 * 16;
 static_assert(PAIR_QUEUE_BYTES <= WAVE_QUEUE_BYTES, "the pair queue lives in the hit queue's LDS region");
 
-// one batch: lane l takes pair head + l of queue TYPE (0 sphere, 1 box), whoever owns it
-template <uint32_t TYPE>
-__device__ __forceinline__ void pairBatch(const Prim *s_prims, const PairQueue &q, uint32_t head, uint32_t nb, uint32_t lane)
+// one batch: lane l takes pair head + l of queue TYPE (0 sphere, 1 box), whoever owns it.  TYPE 2 = the last, mixed
+// batch of a chunk: lanes [0, nb) take the sphere queue's leftovers, lanes [nb, nb + nb2) the box queue's.
+template <uint32_t TYPE, bool FIRST>
+__device__ __forceinline__ void pairBatch(const KParams &p, const Prim *s_prims, const PairQueue &q, uint32_t head, uint32_t nb,
+                                          uint32_t lane, uint32_t head2 = 0u, uint32_t nb2 = 0u)
 {
     wave_lds_fence();
     unsigned long long mykey = KEY_NONE;
     uint32_t owner = 0u;
     float4 mine = make_float4(0, 0, 0, 0);
-    if (lane < nb) {
-        const uint32_t e = q.q[TYPE][(head + lane) & (QCAP - 1u)];
+    if (lane < nb + nb2) {
+        const uint32_t type = (TYPE == 2u) ? (lane < nb ? 0u : 1u) : TYPE;
+        const uint32_t e = (TYPE == 2u && lane >= nb) ? q.q[1][(head2 + lane - nb) & (QCAP - 1u)]
+                                                      : q.q[TYPE == 2u ? 0u : TYPE][(head + lane) & (QCAP - 1u)];
         owner = e & 63u;
         const uint32_t prim = e >> 8;
         const float4 oo = q.org[owner], dd = q.dir[owner];
@@ -407,9 +413,15 @@ __device__ __forceinline__ void pairBatch(const Prim *s_prims, const PairQueue &
         const float4 i0 = iv[0], i1 = iv[1], i2 = iv[2];
         const float inv[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
         f3 ro = o, rd;
+        if (FIRST) {                                         // camera rays: inverseTransform*(eye,1) comes from the host
+            const float4 re = reinterpret_cast<const float4 *>(p.ro_eye)[prim];
+            ro = mk(re.x, re.y, re.z);
+        }
         float t;
         uint32_t face;
-        if (candidateT<false>(TYPE, inv, o, d, ro, rd, t, face)) {
+        const bool ch = candidateT<FIRST>(type, inv, o, d, ro, rd, t, face);
+        if (DEBUG_PAIR) { const uint64_t mm = __ballot(ch); if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicAdd((unsigned long long *)q.dbg + 2 + (TYPE & 1u), (unsigned long long)__popcll(mm)); }
+        if (ch) {
             const float4 f0 = iv[3], f1 = iv[4], f2 = iv[5];          // fwd rows follow the inverse rows
             const float fwd[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
             f3 real;
@@ -436,6 +448,9 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const Prim *s_p
     q.dir[lane] = make_float4(d.x, d.y, d.z, 0.0f);
     uint32_t head[2] = {0u, 0u}, tail[2] = {0u, 0u};        // wave-uniform
     const f3 dinv = approxInverse(d);
+    // slab distances as fma(plane, 1/d, -o/d): one instruction per plane; against (plane - o)/d this moves a plane by
+    // less than 1.2e-6 |o|, far inside the boxes' padding
+    const f3 oinv = FIRST ? mk(0, 0, 0) : mk(-(o.x * dinv.x), -(o.y * dinv.y), -(o.z * dinv.z));
     for (int g = 0; g < p.nG; ++g) {
         const_u32_ptr hp = (const_u32_ptr)(uintptr_t)(p.prims + g);
         const uint32_t type = hp[0];
@@ -444,10 +459,9 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const Prim *s_p
         const_u32_ptr bq = (const_u32_ptr)(uintptr_t)((FIRST ? p.box_eye : p.box_world) + 8 * g);
         const f3 lo = mk(__uint_as_float(bq[0]), __uint_as_float(bq[1]), __uint_as_float(bq[2]));
         const f3 hi = mk(__uint_as_float(bq[4]), __uint_as_float(bq[5]), __uint_as_float(bq[6]));
-        const f3 a = FIRST ? lo : lo - o, b = FIRST ? hi : hi - o;
-        const float x0 = a.x * dinv.x, x1 = b.x * dinv.x;
-        const float y0 = a.y * dinv.y, y1 = b.y * dinv.y;
-        const float z0 = a.z * dinv.z, z1 = b.z * dinv.z;
+        const float x0 = __builtin_fmaf(lo.x, dinv.x, oinv.x), x1 = __builtin_fmaf(hi.x, dinv.x, oinv.x);
+        const float y0 = __builtin_fmaf(lo.y, dinv.y, oinv.y), y1 = __builtin_fmaf(hi.y, dinv.y, oinv.y);
+        const float z0 = __builtin_fmaf(lo.z, dinv.z, oinv.z), z1 = __builtin_fmaf(hi.z, dinv.z, oinv.z);
         const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
         const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
         const bool pass = valid && tn <= tf;
@@ -457,15 +471,28 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const Prim *s_p
         if (type == 0u) {                                    // wave-uniform
             if (pass) q.q[0][(tail[0] + rank) & (QCAP - 1u)] = lane | ((uint32_t)g << 8);
             tail[0] += (uint32_t)__popcll(mask);
-            if (tail[0] - head[0] >= 64u) { pairBatch<0u>(s_prims, q, head[0], 64u, lane); head[0] += 64u; }
+            if (tail[0] - head[0] >= 64u) { pairBatch<0u, FIRST>(p, s_prims, q, head[0], 64u, lane); head[0] += 64u; }
         } else {
             if (pass) q.q[1][(tail[1] + rank) & (QCAP - 1u)] = lane | ((uint32_t)g << 8);
             tail[1] += (uint32_t)__popcll(mask);
-            if (tail[1] - head[1] >= 64u) { pairBatch<1u>(s_prims, q, head[1], 64u, lane); head[1] += 64u; }
+            if (tail[1] - head[1] >= 64u) { pairBatch<1u, FIRST>(p, s_prims, q, head[1], 64u, lane); head[1] += 64u; }
         }
     }
-    if (tail[0] != head[0]) pairBatch<0u>(s_prims, q, head[0], tail[0] - head[0], lane);
-    if (tail[1] != head[1]) pairBatch<1u>(s_prims, q, head[1], tail[1] - head[1], lane);
+    const uint64_t dbg_valid = DEBUG_PAIR ? __ballot(valid) : 0ull;
+    if (DEBUG_PAIR && lane == 0) {
+        atomicAdd(&p.st->dbg[0], (unsigned long long)tail[0]);
+        atomicAdd(&p.st->dbg[1], (unsigned long long)tail[1]);
+        atomicAdd(&p.st->dbg[4], (unsigned long long)__popcll(dbg_valid));
+        atomicAdd(&p.st->dbg[5], (unsigned long long)((tail[0] + 63) / 64 + (tail[1] + 63) / 64));
+        atomicAdd(&p.st->dbg[6], 1ull);
+    }
+    const uint32_t left0 = tail[0] - head[0], left1 = tail[1] - head[1];      // both < 64
+    if (left0 != 0u && left1 != 0u && left0 + left1 <= 64u) {
+        pairBatch<2u, FIRST>(p, s_prims, q, head[0], left0, lane, head[1], left1);   // one mixed batch instead of two partial ones
+    } else {
+        if (left0 != 0u) pairBatch<0u, FIRST>(p, s_prims, q, head[0], left0, lane);
+        if (left1 != 0u) pairBatch<1u, FIRST>(p, s_prims, q, head[1], left1, lane);
+    }
     wave_lds_fence();
     Hit h;
     h.any = false;
@@ -515,6 +542,7 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const Prim *s_prims,
         pq.best = reinterpret_cast<float4 *>(b + 2 * QCAP * 4 + 64 * 8);
         pq.org = reinterpret_cast<float4 *>(b + 2 * QCAP * 4 + 64 * 8 + 64 * 16);
         pq.dir = reinterpret_cast<float4 *>(b + 2 * QCAP * 4 + 64 * 8 + 2 * 64 * 16);
+        pq.dbg = p.st->dbg;
         return nearestHitPairs<FIRST>(p, s_prims, pq, o, d, want, lane);
     }
     Hit h;
@@ -546,8 +574,10 @@ __device__ __forceinline__ uint32_t globalPixel(const KParams &p, uint32_t pl)
 // pixel word whether its previous vertex sampled the lights (a light hit by chance adds nothing), the radiance planes
 // accumulate along the path (every path initialises its entry at bounce 0), and each chunk makes a second pass through
 // the nearest-hit machinery for the shadow rays.
+// 5 waves per SIMD (<= 96 VGPRs) is where the plain kernels sit and what hides their LDS / pool latency: ask for it, so
+// that a few registers more do not silently drop a wave (4 waves: -5 %).
 template <int WG, bool FIRST, int GEOM, int COMPACT, bool NEE = false>
-__global__ __launch_bounds__(WG) void k_bounce(const KParams p, const int bounce)
+__global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(const KParams p, const int bounce)
 {
     constexpr int NW = WG / 64;
     constexpr bool PRIMS_IN_LDS = (GEOM == GEOM_LDS || GEOM == GEOM_QUEUE || GEOM == GEOM_PAIR);   // GEOM_BVH gathers records from global memory (L1/L2)
