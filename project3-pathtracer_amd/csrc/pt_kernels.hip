@@ -588,7 +588,8 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
     const float4 *s_nodes = reinterpret_cast<const float4 *>(smem + prim_bytes);
     const int node_bytes = (GEOM == GEOM_BVH) ? p.nnodes * (int)sizeof(BvhNode) : 0;
     unsigned char *s_queue = smem + prim_bytes + node_bytes;
-    const int queue_bytes = (GEOM == GEOM_QUEUE || GEOM == GEOM_PAIR) ? NW * (int)WAVE_QUEUE_BYTES : 0;
+    constexpr int WAVE_LDS = (GEOM == GEOM_QUEUE) ? (int)WAVE_QUEUE_BYTES : (GEOM == GEOM_PAIR ? (int)PAIR_QUEUE_BYTES : 0);
+    const int queue_bytes = NW * WAVE_LDS;
     float *s_mats = reinterpret_cast<float *>(s_queue + queue_bytes);
     const int mat_words = (p.nM * M_PLANES + 3) & ~3;
     uint32_t *s_scan = reinterpret_cast<uint32_t *>(s_mats + mat_words);   // [2][NW] wave totals, [2] bases
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
 
     WaveQueue wq;
     {
-        unsigned char *b = s_queue + wave * (int)WAVE_QUEUE_BYTES;
+        unsigned char *b = s_queue + wave * WAVE_LDS;
         wq.rec = reinterpret_cast<float4 *>(b);
         wq.key = reinterpret_cast<unsigned long long *>(b + QCAP * 32);
         wq.best = reinterpret_cast<float4 *>(b + QCAP * 32 + 64 * 8);
@@ -1108,7 +1109,7 @@ __global__ __launch_bounds__(256) void k_send_image_to_pbo(pt_uchar4 *pbo, const
 size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg)
 {
     size_t prim = (cfg.geom == GEOM_LDS || cfg.geom == GEOM_QUEUE || cfg.geom == GEOM_PAIR) ? (size_t)p.nG * sizeof(Prim) : 0;
-    size_t queue = (cfg.geom == GEOM_QUEUE || cfg.geom == GEOM_PAIR) ? (size_t)(cfg.workgroup / 64) * WAVE_QUEUE_BYTES : 0;
+    size_t queue = (size_t)(cfg.workgroup / 64) * (cfg.geom == GEOM_QUEUE ? WAVE_QUEUE_BYTES : (cfg.geom == GEOM_PAIR ? PAIR_QUEUE_BYTES : 0));
     if (cfg.geom == GEOM_BVH) prim += (size_t)p.nnodes * sizeof(BvhNode);
     size_t mats = (size_t)((p.nM * M_PLANES + 3) & ~3) * sizeof(float);
     size_t scan = (size_t)(2 * (cfg.workgroup / 64) + 2) * sizeof(uint32_t);
