@@ -153,7 +153,7 @@ void build_bvh(const std::vector<Aabb> &boxes, std::vector<int> &idx, size_t lo,
         }
     }
     if (hi - lo == 1) {
-        nodes[me].prim = idx[lo];
+        nodes[me].prim = idx[lo];          // the caller ORs the primitive type into bit 30
     } else {
         // surface-area heuristic, full sweep: for every axis sort by centroid and take the split that minimises
         // area(left)*count(left) + area(right)*count(right)  (the hierarchy only culls, so any split is correct)
@@ -433,6 +433,8 @@ int configure(pt_ctx *c)
         }
         std::vector<ptd::BvhNode> nodes;
         if (!idx.empty()) build_bvh(boxes, idx, 0, idx.size(), nodes);
+        for (auto &nd : nodes)
+            if (nd.prim >= 0) nd.prim |= (c->geoms[(size_t)nd.prim].type == PT_CUBE ? 1 : 0) << 30;
         k.nnodes = (int)nodes.size();
         if (c->d_bvh) { (void)hipFree(c->d_bvh); c->d_bvh = nullptr; }
         if (nodes.empty()) nodes.push_back(ptd::BvhNode());
@@ -463,7 +465,7 @@ int configure(pt_ctx *c)
     cfg.workgroup = o.workgroup ? o.workgroup : 256;
     // library choice: the pair queue's pre-test is linear in the primitive count, the hierarchy walk logarithmic but
     // divergent: measured crossover near 100 primitives (profiles/r01/crossover_pair_vs_walk.txt)
-    cfg.geom = o.geom_path == 0 ? (k.nG <= 96 ? 4 : 3) : o.geom_path - 1;
+    cfg.geom = o.geom_path == 0 ? (k.nG <= 96 ? 4 : 5) : o.geom_path - 1;
     cfg.compact = o.compaction;
     cfg.nee = k.nlights > 0 ? 1 : 0;             // no lights: nothing to sample, the plain kernels are exact
     k.cull = (k.nG > 32 && !getenv("PT_NO_CULL")) ? 1 : 0;
@@ -655,7 +657,7 @@ int pt_set_options(pt_ctx *c, const pt_options *o)
     const int wg = o->workgroup;
     if (!(wg == 0 || wg == 64 || wg == 128 || wg == 256 || wg == 512 || wg == 1024))
         return fail(PT_ERR_INVALID, "workgroup %d not one of 0,64,128,256,512,1024", wg);
-    if (o->geom_path < 0 || o->geom_path > 5) return fail(PT_ERR_INVALID, "geom_path %d not in 0..5", o->geom_path);
+    if (o->geom_path < 0 || o->geom_path > 6) return fail(PT_ERR_INVALID, "geom_path %d not in 0..6", o->geom_path);
     if (o->row_begin < 0 || o->row_end < o->row_begin) return fail(PT_ERR_INVALID, "tile rows [%d,%d)", o->row_begin, o->row_end);
     if (o->strip_rows < 0 || (o->strip_rows > 0 && (o->strip_world < 1 || o->strip_rank < 0 || o->strip_rank >= o->strip_world)))
         return fail(PT_ERR_INVALID, "strips: rows %d, rank %d of %d", o->strip_rows, o->strip_rank, o->strip_world);
@@ -951,6 +953,7 @@ int pt_get_stats(pt_ctx *c, pt_stats *out)
         fprintf(stderr, "[ptamd] hierarchy walk: %.1f nodes, %.2f leaves per ray; per wave (longest lane): %.1f nodes, %.2f leaves, %.2f rounds\n",
                 (double)h.dbg[0] / (double)h.dbg[2], (double)h.dbg[1] / (double)h.dbg[2], (double)h.dbg[3] / (double)h.dbg[6],
                 (double)h.dbg[4] / (double)h.dbg[6], (double)h.dbg[5] / (double)h.dbg[6]);
+    if (getenv("PT_DEBUG_CLOCK") && h.dbg[7]) fprintf(stderr, "[ptamd] pairs per wave round: %.1f\n", (double)h.dbg[7] / (double)h.dbg[6]);
     return PT_OK;
 }
 

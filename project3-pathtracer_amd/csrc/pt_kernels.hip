@@ -26,7 +26,7 @@ using namespace ptd;
 static constexpr uint32_t DEAD = 0xFFFFFFFFu;
 static constexpr bool DEBUG_CULL = false;
 static constexpr bool DEBUG_PAIR = false;
-static constexpr bool DEBUG_BVH = false;         // count node / leaf visits of the hierarchy walk into IterState::dbg
+static constexpr bool DEBUG_BVH = false;        // count node / leaf visits of the hierarchy walk into IterState::dbg
 static constexpr int MAXSLOT = 8;                 // iterations in flight per launch sequence (pt_internal.h PT_MAX_BATCH)
 static constexpr uint32_t SLOT_SHIFT = 28;        // pixel word = tile-local pixel | slot << 28
 static constexpr uint32_t PIX_MASK = (1u << SLOT_SHIFT) - 1u;
@@ -70,7 +70,11 @@ struct Hit {
 //                      itself AND the hit work then run on full 64-pair batches, each lane on its own pair (ray from
 //                      the owner's LDS slot, primitive record gathered from the LDS copy), results through the same
 //                      64-bit LDS atomic min.  The box test only ever drops pairs the exact test would miss.
-enum { GEOM_SCALAR = 0, GEOM_LDS = 1, GEOM_QUEUE = 2, GEOM_BVH = 3, GEOM_PAIR = 4 };
+//   5  walk + pairs:   large primitive lists.  The scene-spanning primitives go through the pair queue first, which gives
+//                      every ray an upper bound on its hit distance; each lane then walks the hierarchy with box tests
+//                      only, pruned by that bound, and queues the leaves it reaches as (ray, primitive) pairs; the exact
+//                      tests run on full batches as in 4.
+enum { GEOM_SCALAR = 0, GEOM_LDS = 1, GEOM_QUEUE = 2, GEOM_BVH = 3, GEOM_PAIR = 4, GEOM_WALK_PAIR = 5 };
 
 // Conservative cull for large primitive lists: true when NO lane of the wave can hit the primitive, judged by a
 // padded world-space bounding sphere (centre = transform*(0,0,0,1), radius^2 in the record).  It only ever skips
@@ -218,6 +222,7 @@ __device__ __forceinline__ Hit nearestHitBvh(const KParams &p, const Prim *s_pri
             if (prim >= 0) break;
         }
         if (prim < 0) break;
+        prim &= 0x3FFFFFFF;                                  // bit 30 = primitive type (used by the walk + pairs path)
         if (DEBUG_BVH) dbg_leaves++;
         const Prim &P = s_prims[prim];                     // per-lane gather of the record (L1/L2)
         f3 ro = o, rd;
@@ -526,6 +531,181 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const Prim *s_p
     return h;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// GEOM_WALK_PAIR
+// ---------------------------------------------------------------------------------------------------------------
+// append the lanes' pairs (sphere / box flags are per lane, g = primitive index) and run a batch when one is full;
+// every lane of the wave must make the call
+template <bool FIRST>
+__device__ __forceinline__ void pushPairs(const KParams &p, const Prim *prims, const PairQueue &q, uint32_t (&head)[2],
+                                          uint32_t (&tail)[2], bool is_sphere, bool is_box, uint32_t g, uint32_t lane)
+{
+    const uint64_t m0 = __ballot(is_sphere), m1 = __ballot(is_box);
+    if (m0 != 0ull) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+        if (is_sphere) q.q[0][(tail[0] + rank) & (QCAP - 1u)] = lane | (g << 8);
+        tail[0] += (uint32_t)__popcll(m0);
+        if (tail[0] - head[0] >= 64u) { pairBatch<0u, FIRST>(p, prims, q, head[0], 64u, lane); head[0] += 64u; }
+    }
+    if (m1 != 0ull) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+        if (is_box) q.q[1][(tail[1] + rank) & (QCAP - 1u)] = lane | (g << 8);
+        tail[1] += (uint32_t)__popcll(m1);
+        if (tail[1] - head[1] >= 64u) { pairBatch<1u, FIRST>(p, prims, q, head[1], 64u, lane); head[1] += 64u; }
+    }
+}
+template <bool FIRST>
+__device__ __forceinline__ void flushPairs(const KParams &p, const Prim *prims, const PairQueue &q, uint32_t (&head)[2],
+                                           uint32_t (&tail)[2], uint32_t lane)
+{
+    const uint32_t left0 = tail[0] - head[0], left1 = tail[1] - head[1];      // both < 64
+    if (left0 != 0u && left1 != 0u && left0 + left1 <= 64u) {
+        pairBatch<2u, FIRST>(p, prims, q, head[0], left0, lane, head[1], left1);
+    } else {
+        if (left0 != 0u) pairBatch<0u, FIRST>(p, prims, q, head[0], left0, lane);
+        if (left1 != 0u) pairBatch<1u, FIRST>(p, prims, q, head[1], left1, lane);
+    }
+    head[0] = tail[0];
+    head[1] = tail[1];
+}
+
+// Must be entered by all 64 lanes of the wave.  prims: global records (gathered per lane through L1/L2).
+template <bool FIRST>
+__device__ __forceinline__ Hit nearestHitWalkPairs(const KParams &p, const Prim *prims, const float4 *s_nodes, const PairQueue q,
+                                                   f3 o, f3 d, bool valid, uint32_t lane)
+{
+    q.key[lane] = KEY_NONE;
+    q.org[lane] = make_float4(o.x, o.y, o.z, 0.0f);
+    q.dir[lane] = make_float4(d.x, d.y, d.z, 0.0f);
+    uint32_t head[2] = {0u, 0u}, tail[2] = {0u, 0u};        // wave-uniform
+    const f3 dinv = approxInverse(d);
+    const f3 oinv = mk(-(o.x * dinv.x), -(o.y * dinv.y), -(o.z * dinv.z));
+    // 1. the scene-spanning primitives (walls, big lights), wave-uniformly: box pre-test, pairs
+    for (int k = 0; k < p.nbig; ++k) {
+        const int g = p.big[k];
+        const_u32_ptr hp = (const_u32_ptr)(uintptr_t)(p.prims + g);
+        const uint32_t type = hp[0];
+        if (type > 1u) continue;
+        const_u32_ptr bq = (const_u32_ptr)(uintptr_t)(p.box_world + 8 * g);
+        const float x0 = __builtin_fmaf(__uint_as_float(bq[0]), dinv.x, oinv.x), x1 = __builtin_fmaf(__uint_as_float(bq[4]), dinv.x, oinv.x);
+        const float y0 = __builtin_fmaf(__uint_as_float(bq[1]), dinv.y, oinv.y), y1 = __builtin_fmaf(__uint_as_float(bq[5]), dinv.y, oinv.y);
+        const float z0 = __builtin_fmaf(__uint_as_float(bq[2]), dinv.z, oinv.z), z1 = __builtin_fmaf(__uint_as_float(bq[6]), dinv.z, oinv.z);
+        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        const bool pass = valid && tn <= tf;
+        pushPairs<FIRST>(p, prims, q, head, tail, pass && type == 0u, pass && type == 1u, (uint32_t)g, lane);
+    }
+    flushPairs<FIRST>(p, prims, q, head, tail, lane);
+    wave_lds_fence();
+    // 2. the hierarchy: box tests only, pruned by the distance of the best hit so far (reported distances fall short of
+    // the true ones by getPointOnRay's epsilon: the slack covers it), leaves become pairs
+    float tmax = __builtin_inff();
+    {
+        const unsigned long long k0 = q.key[lane];
+        if (k0 != KEY_NONE) tmax = __uint_as_float((uint32_t)(k0 >> 32));
+    }
+    const uint32_t nn = (uint32_t)p.nnodes;
+    uint32_t i = valid ? 0u : nn;
+    uint32_t dbg_nodes = 0, dbg_leaves = 0, dbg_outer = 0, dbg_prev = 0, dbg_trips = 0;
+    for (;;) {
+        // A lane keeps walking past the leaves it reaches (they need no work here) and only stops when it has collected
+        // four or left the tree: breaking at every leaf would make the wave wait for its slowest lane once per leaf
+        // (measured: 141 loop trips per wave against 62 for the longest single walk).
+        int l0 = -1, l1 = -1, l2 = -1, l3 = -1;
+        if (DEBUG_BVH) dbg_outer++;
+        while (i < nn) {
+            if (DEBUG_BVH) dbg_nodes++;
+            const float4 a = s_nodes[2 * i], b = s_nodes[2 * i + 1];
+            const float x0 = __builtin_fmaf(a.x, dinv.x, oinv.x), x1 = __builtin_fmaf(b.x, dinv.x, oinv.x);
+            const float y0 = __builtin_fmaf(a.y, dinv.y, oinv.y), y1 = __builtin_fmaf(b.y, dinv.y, oinv.y);
+            const float z0 = __builtin_fmaf(a.z, dinv.z, oinv.z), z1 = __builtin_fmaf(b.z, dinv.z, oinv.z);
+            const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+            const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+            if (!(tn <= tf) || tn * 0.999f - 1e-3f > tmax) {
+                i = __float_as_uint(a.w);
+                continue;
+            }
+            i = i + 1u;
+            const int pr = (int)__float_as_uint(b.w);
+            if (pr >= 0) {
+                l3 = l2; l2 = l1; l1 = l0; l0 = pr;
+                if (l3 >= 0) break;
+            }
+        }
+        const bool leaf = l0 >= 0;
+        if (DEBUG_BVH) dbg_leaves += (l0 >= 0) + (l1 >= 0) + (l2 >= 0) + (l3 >= 0);
+        if (DEBUG_BVH) {
+            uint32_t r = dbg_nodes - dbg_prev;
+            dbg_prev = dbg_nodes;
+            for (int s = 32; s > 0; s >>= 1) r = max(r, (uint32_t)__shfl_xor((int)r, s));
+            dbg_trips += r;
+        }
+        if (__ballot(leaf) == 0ull) break;                   // every lane has left the tree
+        const uint32_t done_before = head[0] + head[1];
+        {
+            const uint32_t type = (uint32_t)l0 >> 30, g = (uint32_t)l0 & 0x3FFFFFFFu;
+            pushPairs<FIRST>(p, prims, q, head, tail, l0 >= 0 && type == 0u, l0 >= 0 && type == 1u, g, lane);
+        }
+        if (__ballot(l1 >= 0) != 0ull) {
+            const uint32_t type = (uint32_t)l1 >> 30, g = (uint32_t)l1 & 0x3FFFFFFFu;
+            pushPairs<FIRST>(p, prims, q, head, tail, l1 >= 0 && type == 0u, l1 >= 0 && type == 1u, g, lane);
+        }
+        if (__ballot(l2 >= 0) != 0ull) {
+            const uint32_t type = (uint32_t)l2 >> 30, g = (uint32_t)l2 & 0x3FFFFFFFu;
+            pushPairs<FIRST>(p, prims, q, head, tail, l2 >= 0 && type == 0u, l2 >= 0 && type == 1u, g, lane);
+        }
+        if (__ballot(l3 >= 0) != 0ull) {
+            const uint32_t type = (uint32_t)l3 >> 30, g = (uint32_t)l3 & 0x3FFFFFFFu;
+            pushPairs<FIRST>(p, prims, q, head, tail, l3 >= 0 && type == 0u, l3 >= 0 && type == 1u, g, lane);
+        }
+        if (head[0] + head[1] != done_before) {              // a batch ran: the bound may have come down
+            const unsigned long long k1 = q.key[lane];
+            if (k1 != KEY_NONE) tmax = __uint_as_float((uint32_t)(k1 >> 32));
+        }
+    }
+    flushPairs<FIRST>(p, prims, q, head, tail, lane);
+    wave_lds_fence();
+    if (DEBUG_BVH) {
+        uint32_t mn = dbg_nodes, ml = dbg_leaves, mo = dbg_outer;
+        for (int s = 32; s > 0; s >>= 1) {
+            mn = max(mn, (uint32_t)__shfl_xor((int)mn, s));
+            ml = max(ml, (uint32_t)__shfl_xor((int)ml, s));
+            mo = max(mo, (uint32_t)__shfl_xor((int)mo, s));
+        }
+        if (valid) { atomicAdd(&p.st->dbg[0], (unsigned long long)dbg_nodes); atomicAdd(&p.st->dbg[1], (unsigned long long)dbg_leaves); atomicAdd(&p.st->dbg[2], 1ull); }
+        if (lane == 0) {
+            atomicAdd(&p.st->dbg[3], (unsigned long long)dbg_trips);
+            atomicAdd(&p.st->dbg[4], (unsigned long long)ml);
+            atomicAdd(&p.st->dbg[5], (unsigned long long)mo);
+            atomicAdd(&p.st->dbg[6], 1ull);
+            atomicAdd(&p.st->dbg[7], (unsigned long long)(tail[0] + tail[1]));
+        }
+    }
+    Hit h;
+    h.any = false;
+    h.material = 0;
+    h.prim = 0;
+    h.t = 0.0f;
+    h.p = mk(0, 0, 0);
+    h.n = mk(0, 0, 0);
+    const unsigned long long k = q.key[lane];
+    if (valid && k != KEY_NONE) {
+        const float4 b = q.best[lane];
+        const uint32_t meta = __float_as_uint(b.w);
+        const uint32_t prim = (meta >> 8) & 0xFFFFFu;
+        const uint32_t face = meta >> 28;
+        const Prim &P = prims[prim];
+        h.any = true;
+        h.prim = prim;
+        h.t = __uint_as_float((uint32_t)(k >> 32));
+        h.p = mk(b.x, b.y, b.z);
+        h.material = P.material;
+        if (P.type == 0u) h.n = sphereNormal(h.p, mk(P.cx, P.cy, P.cz));
+        else h.n = boxNormal(P.fwd, face);
+    }
+    return h;
+}
+
 // nearest hit of (o, d) for the lanes with want == true, by the GEOM path.  Every lane of the wave must make the call
 // (the hit queue uses all 64 lanes as workers whatever their own ray).
 template <int GEOM, bool FIRST>
@@ -533,7 +713,7 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const Prim *s_prims,
                                           f3 o, f3 d, bool want, uint32_t lane)
 {
     if (GEOM == GEOM_QUEUE) return nearestHitQueued<FIRST>(p, s_prims, wq, o, d, want, lane);
-    if (GEOM == GEOM_PAIR) {
+    if (GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR) {
         PairQueue pq;
         unsigned char *b = reinterpret_cast<unsigned char *>(wq.rec);         // same LDS region as the hit queue
         pq.q[0] = reinterpret_cast<uint32_t *>(b);
@@ -543,6 +723,7 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const Prim *s_prims,
         pq.org = reinterpret_cast<float4 *>(b + 2 * QCAP * 4 + 64 * 8 + 64 * 16);
         pq.dir = reinterpret_cast<float4 *>(b + 2 * QCAP * 4 + 64 * 8 + 2 * 64 * 16);
         pq.dbg = p.st->dbg;
+        if (GEOM == GEOM_WALK_PAIR) return nearestHitWalkPairs<FIRST>(p, p.prims, s_nodes, pq, o, d, want, lane);
         return nearestHitPairs<FIRST>(p, s_prims, pq, o, d, want, lane);
     }
     Hit h;
@@ -586,9 +767,10 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
     Prim *s_prims = reinterpret_cast<Prim *>(smem);
     const int prim_bytes = PRIMS_IN_LDS ? p.nG * (int)sizeof(Prim) : 0;
     const float4 *s_nodes = reinterpret_cast<const float4 *>(smem + prim_bytes);
-    const int node_bytes = (GEOM == GEOM_BVH) ? p.nnodes * (int)sizeof(BvhNode) : 0;
+    const int node_bytes = (GEOM == GEOM_BVH || GEOM == GEOM_WALK_PAIR) ? p.nnodes * (int)sizeof(BvhNode) : 0;
     unsigned char *s_queue = smem + prim_bytes + node_bytes;
-    constexpr int WAVE_LDS = (GEOM == GEOM_QUEUE) ? (int)WAVE_QUEUE_BYTES : (GEOM == GEOM_PAIR ? (int)PAIR_QUEUE_BYTES : 0);
+    constexpr int WAVE_LDS = (GEOM == GEOM_QUEUE) ? (int)WAVE_QUEUE_BYTES
+                             : ((GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR) ? (int)PAIR_QUEUE_BYTES : 0);
     const int queue_bytes = NW * WAVE_LDS;
     float *s_mats = reinterpret_cast<float *>(s_queue + queue_bytes);
     const int mat_words = (p.nM * M_PLANES + 3) & ~3;
@@ -612,7 +794,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
         uint4 *dst = reinterpret_cast<uint4 *>(s_prims);
         for (int k = tid; k < p.nG * 8; k += WG) dst[k] = src[k];
     }
-    if (GEOM == GEOM_BVH) {
+    if (GEOM == GEOM_BVH || GEOM == GEOM_WALK_PAIR) {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.bvh);
         uint4 *dst = reinterpret_cast<uint4 *>(smem + prim_bytes);
         for (int k = tid; k < p.nnodes * 2; k += WG) dst[k] = src[k];
@@ -1109,8 +1291,9 @@ __global__ __launch_bounds__(256) void k_send_image_to_pbo(pt_uchar4 *pbo, const
 size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg)
 {
     size_t prim = (cfg.geom == GEOM_LDS || cfg.geom == GEOM_QUEUE || cfg.geom == GEOM_PAIR) ? (size_t)p.nG * sizeof(Prim) : 0;
-    size_t queue = (size_t)(cfg.workgroup / 64) * (cfg.geom == GEOM_QUEUE ? WAVE_QUEUE_BYTES : (cfg.geom == GEOM_PAIR ? PAIR_QUEUE_BYTES : 0));
-    if (cfg.geom == GEOM_BVH) prim += (size_t)p.nnodes * sizeof(BvhNode);
+    size_t queue = (size_t)(cfg.workgroup / 64) * (cfg.geom == GEOM_QUEUE ? WAVE_QUEUE_BYTES
+                                                   : ((cfg.geom == GEOM_PAIR || cfg.geom == GEOM_WALK_PAIR) ? PAIR_QUEUE_BYTES : 0));
+    if (cfg.geom == GEOM_BVH || cfg.geom == GEOM_WALK_PAIR) prim += (size_t)p.nnodes * sizeof(BvhNode);
     size_t mats = (size_t)((p.nM * M_PLANES + 3) & ~3) * sizeof(float);
     size_t scan = (size_t)(2 * (cfg.workgroup / 64) + 2) * sizeof(uint32_t);
     static const size_t extra = getenv("PT_EXTRA_LDS") ? (size_t)atol(getenv("PT_EXTRA_LDS")) : 0;   // occupancy experiments
@@ -1138,6 +1321,7 @@ static const void *bounce_fn_geom(bool first, int compact, int nee)
 template <int WG>
 static const void *bounce_fn_wg(bool first, int geom, int compact, int nee)
 {
+    if (geom == GEOM_WALK_PAIR) return bounce_fn_geom<WG, GEOM_WALK_PAIR>(first, compact, nee);
     if (geom == GEOM_PAIR) return bounce_fn_geom<WG, GEOM_PAIR>(first, compact, nee);
     if (geom == GEOM_BVH) return bounce_fn_geom<WG, GEOM_BVH>(first, compact, nee);
     if (geom == GEOM_QUEUE) return bounce_fn_geom<WG, GEOM_QUEUE>(first, compact, nee);

@@ -112,7 +112,7 @@ def test_cloud_256_primitives(pkg):
 
 
 @pytest.mark.parametrize("rotat", [0, 1])
-@pytest.mark.parametrize("geom_path", [1, 4, 5])
+@pytest.mark.parametrize("geom_path", [1, 4, 5, 6])
 def test_cloud_cull_is_conservative(pkg, rotat, geom_path):
     """Large primitive lists are culled (geom_path 1: per wave with padded bounding spheres; 4: per lane with a
     padded bounding-box hierarchy).  Culling may only skip primitives that cannot be hit, so a bigger sample of
@@ -208,7 +208,7 @@ def test_geometry_paths_identical(pkg):
     assert np.array_equal(a, d) and la == ld
 
 
-@pytest.mark.parametrize("geom_path", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("geom_path", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("scene,depth,rotat", [("sampleScene.txt", 6, 0), ("cornell_glass.txt", 10, 1),
                                                ("cloud256.txt", 5, 1)])
 def test_every_geometry_path_against_oracle(pkg, geom_path, scene, depth, rotat):
@@ -413,7 +413,7 @@ def test_random_scenes_bit_exact(pkg, seed):
     ma = (O.Material * len(mats))(*mats)
     cam = O.make_camera(W, H, eye, view, up, fovy)
     ref, live = O.render(ga, len(geoms), ma, len(mats), cam, depth, iters=iters, rr_start=3, seed=seed)
-    for geom_path in (1, 3, 4, 5) if n_prims <= 32 else (1, 2, 4, 5):
+    for geom_path in (1, 3, 4, 5, 6) if n_prims <= 32 else (1, 2, 4, 5, 6):
         with pkg.Renderer(0) as r:
             r.set_options(depth=depth, rr_start=3, seed=seed, geom_path=geom_path)
             r.set_scene(C.cast(ga, C.POINTER(pkg.StaticGeom)), len(geoms), C.cast(ma, C.POINTER(pkg.Material)), len(mats))
@@ -500,7 +500,7 @@ def test_direct_lighting_matches_oracle(pkg, scene, rotat, depth, iters):
     assert int(st0.shadow_rays) == 0 and not np.array_equal(plain, gpu)
 
 
-@pytest.mark.parametrize("geom_path", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("geom_path", [1, 2, 3, 4, 5, 6])
 def test_direct_lighting_on_every_geometry_path(pkg, geom_path):
     W, H, depth = 80, 60, 4
     cpu, lc, shadows = cpu_render_dl("sampleScene_spec.txt", W, H, depth, iters=2, rotat=1)
