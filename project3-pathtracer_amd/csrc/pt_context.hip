@@ -470,7 +470,13 @@ int configure(pt_ctx *c)
     cfg.nee = k.nlights > 0 ? 1 : 0;             // no lights: nothing to sample, the plain kernels are exact
     k.cull = (k.nG > 32 && !getenv("PT_NO_CULL")) ? 1 : 0;
     k.nshard = (cfg.compact == 1) ? pt::NSHARD : 1;
-    const size_t lds = pt::bounce_lds_bytes(k, cfg);
+    size_t lds = pt::bounce_lds_bytes(k, cfg);
+    if (lds > 160 * 1024 && o.geom_path == 0) {
+        // the hierarchy (32 B per node, 2 nodes per primitive) no longer fits the CU's LDS: fall back to the scalar
+        // loop with the per-wave bounding-sphere cull, which needs none
+        cfg.geom = 0;
+        lds = pt::bounce_lds_bytes(k, cfg);
+    }
     if (lds > 160 * 1024) return fail(PT_ERR_INVALID, "scene needs %zu B of LDS per workgroup (> 160 KiB)", lds);
     int per_cu = pt::bounce_max_blocks_per_cu(k, cfg);
     if (per_cu < 1) return fail(PT_ERR_HIP, "occupancy query failed for workgroup=%d (%s)", cfg.workgroup,

@@ -1346,6 +1346,14 @@ int bounce_max_blocks_per_cu(const KParams &p, const LaunchCfg &cfg)
     const void *fn = select_bounce(cfg, false);
     int nb = 0;
     if (!fn) return 0;
+    // more than 64 KiB of dynamic LDS per workgroup has to be asked for (large hierarchies)
+    const size_t lds = bounce_lds_bytes(p, cfg);
+    if (lds > 64 * 1024) {
+        const void *f0 = select_bounce(cfg, true);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(f0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return 0;
+    }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, cfg.workgroup, bounce_lds_bytes(p, cfg)) != hipSuccess)
         return 0;
     return nb;

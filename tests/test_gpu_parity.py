@@ -618,3 +618,25 @@ def test_multi_device_handle_with_strips(pkg, ndev, strip):
         assert np.array_equal(host, ref4)
     finally:
         L.pt_multi_destroy(m)
+
+
+@pytest.mark.parametrize("n_prims,paths", [(1500, (0, 4)), (6000, (0,))])
+def test_very_large_primitive_lists(pkg, n_prims, paths):
+    """1 500 primitives: the hierarchy needs more than 64 KiB of LDS per workgroup (asked for explicitly); 6 000: it no
+    longer fits the CU at all and the library falls back to the scalar loop with the per-wave cull.  Same bits."""
+    geoms, mats, eye, view, up, fovy = _random_scene(4242, n_prims)
+    W, H, depth = 48, 32, 3
+    ga = (O.StaticGeom * len(geoms))(*geoms)
+    ma = (O.Material * len(mats))(*mats)
+    cam = O.make_camera(W, H, eye, view, up, fovy)
+    ref, live = O.render(ga, n_prims, ma, len(mats), cam, depth, iters=1)
+    for gp in paths:
+        with pkg.Renderer(0) as r:
+            r.set_options(depth=depth, geom_path=gp)
+            r.set_scene(C.cast(ga, C.POINTER(pkg.StaticGeom)), n_prims, C.cast(ma, C.POINTER(pkg.Material)), len(mats))
+            r.set_camera(pkg.CameraData.from_buffer_copy(cam))
+            r.clear_image()
+            r.render(1, 1)
+            img = r.download_image()
+            st = r.stats()
+        check(img, ref, [int(x) for x in st.live_in[:depth]], [int(x) for x in live], f"{n_prims} primitives geom_path={gp}")
