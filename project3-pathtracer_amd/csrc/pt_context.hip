@@ -952,6 +952,10 @@ int pt_get_stats(pt_ctx *c, pt_stats *out)
                 (double)h.clk[0] / (double)h.clk[1] * 100.0);
     out->bounce_launches = c->bounce_launches;
     out->shadow_rays = h.shadow_rays;
+    if (getenv("PT_DEBUG_PHASE") && h.dbg[3] && h.dbg[7])
+        fprintf(stderr, "[ptamd] shader clocks per chunk (wave latency): bounce 0: load/gen %.0f, nearest hit %.0f, shade+write %.0f; later: %.0f, %.0f, %.0f\n",
+                (double)h.dbg[0] / h.dbg[3], (double)h.dbg[1] / h.dbg[3], (double)h.dbg[2] / h.dbg[3],
+                (double)h.dbg[4] / h.dbg[7], (double)h.dbg[5] / h.dbg[7], (double)h.dbg[6] / h.dbg[7]);
     if (getenv("PT_DEBUG_PAIR") && h.dbg[4])
         fprintf(stderr, "[ptamd] pair queue: per ray %.2f sphere + %.2f box pairs; candidates that hit: %.2f + %.2f per ray; batches per wave round %.2f\n",
                 (double)h.dbg[0] / h.dbg[4], (double)h.dbg[1] / h.dbg[4], (double)h.dbg[2] / h.dbg[4], (double)h.dbg[3] / h.dbg[4], (double)h.dbg[5] / h.dbg[6]);

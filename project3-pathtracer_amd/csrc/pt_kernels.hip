@@ -24,8 +24,19 @@ namespace pt {
 using namespace ptd;
 
 static constexpr uint32_t DEAD = 0xFFFFFFFFu;
+// Ray prefetch by LDS-DMA (later bounces of the pair-queue path).  Measured on config 2: a chunk's wave latency falls by
+// 19 % (the top-of-chunk wait, 35 % of it, was mostly for the acknowledgement of the wave's own previous stores: vmcnt
+// counts loads and stores together), throughput moves +1 % (+6 % with axis-aligned walls): the kernel is VALU-issue-
+// bound and the resident waves already cover most of the wait.  Not used by the large-scene path, where its 10 KiB of
+// LDS cost a workgroup per CU (-15 %).
+#ifndef PT_RAY_PREFETCH
+#define PT_RAY_PREFETCH 1
+#endif
+static constexpr uint32_t RAY_PENDING = 0xFFFFFFFFu;   // pixel word of a prefetch slot whose record has not landed yet
+static constexpr int RAY_LDS_BYTES = 2560;        // one wave's 64 prefetched ray records (40 B each)
 static constexpr bool DEBUG_CULL = false;
 static constexpr bool DEBUG_PAIR = false;
+static constexpr bool DEBUG_PHASE = false;       // per-wave shader-clock stamps between the phases of a chunk -> IterState::dbg
 static constexpr bool DEBUG_BVH = false;        // count node / leaf visits of the hierarchy walk into IterState::dbg
 static constexpr int MAXSLOT = 8;                 // iterations in flight per launch sequence (pt_internal.h PT_MAX_BATCH)
 static constexpr uint32_t SLOT_SHIFT = 28;        // pixel word = tile-local pixel | slot << 28
@@ -775,10 +786,17 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
     float *s_mats = reinterpret_cast<float *>(s_queue + queue_bytes);
     const int mat_words = (p.nM * M_PLANES + 3) & ~3;
     uint32_t *s_scan = reinterpret_cast<uint32_t *>(s_mats + mat_words);   // [2][NW] wave totals, [2] bases
+    constexpr bool PREFETCH = PT_RAY_PREFETCH && GEOM == GEOM_PAIR && !FIRST && COMPACT != 0;
+    constexpr int SCAN_WORDS = (2 * NW + 2 + 3) & ~3;
+    unsigned char *const s_ray = reinterpret_cast<unsigned char *>(s_scan + SCAN_WORDS) + (threadIdx.x >> 6) * RAY_LDS_BYTES;   // [a 1024][b 1024][c.x 256][c.y 256]
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+    lds_vu32 *const s_ray_pix = (lds_vu32 *)(__attribute__((address_space(3))) unsigned char *)(s_ray + 2304);
+    const uint32_t s_ray_lds = (uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_ray);     // LDS byte address, wave-uniform
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: chunk bookkeeping runs on the scalar unit
 
     WaveQueue wq;
     {
@@ -821,17 +839,21 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
 
     // Input: the live rays of this bounce sit in up to NSHARD dense segments of the pool (one per reservation
     // counter).  A wave works on 64-ray chunks; chunk -> (segment, offset) is wave-uniform scalar arithmetic.
-    uint32_t seg_n[NSHARD], seg_c0[NSHARD + 1];          // rays per segment, first chunk of each segment
-    seg_c0[0] = 0;
-#pragma unroll
-    for (int sh = 0; sh < NSHARD; ++sh) {
+    // The per-segment ray counts sit in a small LDS table; a wave visits its chunks in increasing order, so it keeps a
+    // cursor (segment, first chunk of it, rays in it) in scalar registers and only touches the table when it crosses
+    // into the next segment.
+    __shared__ uint32_t s_segn[NSHARD];
+    if (tid < NSHARD) {
         uint32_t ns = 0;
-        if (FIRST || COMPACT == 0) ns = (sh == 0) ? (uint32_t)p.npix * (uint32_t)p.nslot : 0u;
-        else if (sh < p.nshard) ns = st->counts[cnt_index(bounce, sh)];
-        seg_n[sh] = ns;
-        seg_c0[sh + 1] = seg_c0[sh] + ((ns + 63u) >> 6);
+        if (FIRST || COMPACT == 0) ns = (tid == 0) ? (uint32_t)p.npix * (uint32_t)p.nslot : 0u;
+        else if (tid < p.nshard) ns = st->counts[cnt_index(bounce, tid)];
+        s_segn[tid] = ns;
     }
-    const uint32_t total_chunks = seg_c0[NSHARD];
+    __syncthreads();
+    uint32_t total_chunks = 0;
+#pragma unroll
+    for (int k = 0; k < NSHARD; ++k) total_chunks += ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_segn[k]) + 63u) >> 6;
+    struct Cursor { uint32_t sh, c0, nseg; };
     // the segment this wave (COMPACT 1) / workgroup (COMPACT 2) appends its survivors to
     const uint32_t gwave = blockIdx.x * NW + wave;
     const uint32_t myshard = (COMPACT == 1 ? gwave : blockIdx.x) & (uint32_t)(p.nshard - 1);
@@ -841,17 +863,53 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
     uint32_t live_count = 0;      // COMPACT 0: rays this wave found alive on entry
     uint32_t shadow_count = 0;    // NEE: shadow rays this wave traced
     int round = 0;
+    unsigned long long ph[5] = {0, 0, 0, 0, 0};
+    // pool slot of this lane in the chunk workgroup-round R2 gives this wave, and whether there is a ray in it
+    auto locate = [&](Cursor &cu, uint32_t R2, uint32_t &slot_i) -> bool {
+        const uint32_t chunk = R2 * NW + wave;
+        while (cu.sh + 1u < (uint32_t)NSHARD && chunk >= cu.c0 + ((cu.nseg + 63u) >> 6)) {
+            cu.c0 += (cu.nseg + 63u) >> 6;
+            cu.sh += 1u;
+            cu.nseg = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_segn[cu.sh]);
+        }
+        const uint32_t idx = (chunk - cu.c0) * 64u + lane;       // index inside the segment
+        slot_i = cu.sh * p.segcap + idx;                          // pool slot (FIRST / COMPACT 0: sh == 0, i == idx)
+        return chunk < total_chunks && idx < cu.nseg;
+    };
+    Cursor cur = {0u, 0u, (uint32_t)__builtin_amdgcn_readfirstlane((int)s_segn[0])}, nxt = cur;
+    // Ray prefetch (later bounces): the NEXT chunk's records travel pool -> LDS by LDS-DMA (global_load_lds: no VGPR
+    // destination, lane-linear image = exactly the SoA pool layout) while this chunk is being traced, so a wave does not
+    // sit out the pool's read latency at the top of every chunk (measured: 35 % of a chunk's wave latency).
+    auto prefetch = [&](uint32_t R2) {
+        uint32_t j;
+        // arrival is detected through LDS itself (a sentinel in the pixel-word plane, the last piece to land: no live
+        // ray has an all-ones pixel word), not through vmcnt: that counter also holds this wave's outstanding STORES,
+        // and waiting for those costs thousands of cycles per chunk
+        s_ray_pix[lane] = RAY_PENDING;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (locate(nxt, R2, j)) {
+            // inline asm: hipcc orders every later LDS access behind a builtin LDS-DMA with s_waitcnt vmcnt(0) -- which
+            // would also wait for this wave's outstanding stores, the very thing to avoid.  M0 = wave-uniform LDS byte
+            // address of the destination, written in the statement that uses it.
+            unsigned keep;
+            const float4 *ga = in.a + j, *gb = in.b + j;
+            const float *gc = reinterpret_cast<const float *>(in.c + j);
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(ga), "s"(s_ray_lds) : "memory");
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gb), "s"(s_ray_lds + 1024u) : "memory");
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gc), "s"(s_ray_lds + 2048u) : "memory");
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gc + 1), "s"(s_ray_lds + 2304u) : "memory");
+        }
+    };
+    if (PREFETCH) prefetch(blockIdx.x);
     for (uint32_t R = blockIdx.x; R * NW < total_chunks; R += gridDim.x, ++round) {     // workgroup-uniform trip count
-        const uint32_t chunk = R * NW + wave;
-        uint32_t sh = 0;
-#pragma unroll
-        for (int k = 1; k < NSHARD; ++k) sh += (chunk >= seg_c0[k]) ? 1u : 0u;
-        uint32_t nseg = seg_n[0], c0 = 0;
-#pragma unroll
-        for (int k = 1; k < NSHARD; ++k) if (sh == (uint32_t)k) { nseg = seg_n[k]; c0 = seg_c0[k]; }
-        const uint32_t idx = (chunk - c0) * 64u + lane;          // index inside the segment
-        const uint32_t i = sh * p.segcap + idx;                   // pool slot (FIRST / COMPACT 0: sh == 0, i == idx)
-        bool valid = chunk < total_chunks && idx < nseg;
+        const unsigned long long tc0 = DEBUG_PHASE ? __builtin_amdgcn_s_memtime() : 0ull;
+        uint32_t i;
+        bool valid = locate(cur, R, i);
+        const bool in_pool = valid;                               // the slot exists (COMPACT 0: it may hold a dead ray)
         f3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(1, 1, 1);
         uint32_t pix = 0;
         if (FIRST) {
@@ -881,6 +939,23 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
                 o = eye;
                 d = normalize(P - eye);
             }
+        } else if (PREFETCH) {
+            for (;;) {                                                  // this chunk's records have landed in LDS
+                pix = s_ray_pix[lane];
+                if (__ballot(valid && pix == RAY_PENDING) == 0ull) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            asm volatile("" ::: "memory");
+            if (valid) {
+                const float4 a = reinterpret_cast<const float4 *>(s_ray)[lane];
+                const float4 b = reinterpret_cast<const float4 *>(s_ray + 1024)[lane];
+                const float cx = reinterpret_cast<const float *>(s_ray + 2048)[lane];
+                o = mk(a.x, a.y, a.z);
+                d = mk(a.w, b.x, b.y);
+                T = mk(b.z, b.w, cx);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // ... and are in registers: the slot is free again
+            prefetch(R + gridDim.x);
         } else {
             if (valid) {
                 const float2 c = in.c[i];
@@ -898,7 +973,9 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
         if (COMPACT == 0) live_count += (uint32_t)__popcll(__ballot(valid));
 
         bool alive = false;
+        const unsigned long long c1 = DEBUG_PHASE ? __builtin_amdgcn_s_memtime() : 0ull;
         const Hit h = nearestHit<GEOM, FIRST>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane);
+        const unsigned long long c2 = DEBUG_PHASE ? __builtin_amdgcn_s_memtime() : 0ull;
         f3 L = mk(0, 0, 0);               // radiance this vertex adds to the path's sample
         // direct lighting: the shadow ray this lane wants traced and what it is worth if the light is visible
         bool want_shadow = false;
@@ -1056,6 +1133,8 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
             lp[2] = L.z;
         }
 
+        const unsigned long long c3 = DEBUG_PHASE ? __builtin_amdgcn_s_memtime() : 0ull;
+        if (DEBUG_PHASE) { ph[0] += c1 - tc0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[4] += 1; }
         if (last) continue;      // wave-uniform: nothing survives the last bounce
 
         if (COMPACT != 0) {
@@ -1094,7 +1173,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
             }
         } else {
             // no compaction (validation / ablation mode): the ray keeps slot i, dead slots are tagged
-            if (chunk < total_chunks && idx < nseg) {
+            if (in_pool) {
                 if (alive) {
                     out.a[i] = make_float4(o.x, o.y, o.z, d.x);
                     out.b[i] = make_float4(d.y, d.z, T.x, T.y);
@@ -1110,6 +1189,13 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
     }
     if (NEE) {
         if (lane == 0 && shadow_count) atomicAdd(&st->shadow_rays, (unsigned long long)shadow_count);
+    }
+    if (DEBUG_PHASE && lane == 0) {
+        const int base = FIRST ? 0 : 4;
+        atomicAdd(&st->dbg[base + 0], ph[0]);
+        atomicAdd(&st->dbg[base + 1], ph[1]);
+        atomicAdd(&st->dbg[base + 2], ph[2]);
+        atomicAdd(&st->dbg[base + 3], ph[4]);
     }
     if (bounce == 1 && blockIdx.x == 0 && tid == 0) {      // clock diagnostics (one thread per launch)
         st->clk[0] = __builtin_amdgcn_s_memtime() - clk0;
@@ -1295,7 +1381,8 @@ size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg)
                                                    : ((cfg.geom == GEOM_PAIR || cfg.geom == GEOM_WALK_PAIR) ? PAIR_QUEUE_BYTES : 0));
     if (cfg.geom == GEOM_BVH || cfg.geom == GEOM_WALK_PAIR) prim += (size_t)p.nnodes * sizeof(BvhNode);
     size_t mats = (size_t)((p.nM * M_PLANES + 3) & ~3) * sizeof(float);
-    size_t scan = (size_t)(2 * (cfg.workgroup / 64) + 2) * sizeof(uint32_t);
+    size_t scan = (size_t)((2 * (cfg.workgroup / 64) + 2 + 3) & ~3) * sizeof(uint32_t);
+    if (PT_RAY_PREFETCH && cfg.geom == GEOM_PAIR && cfg.compact != 0) scan += (size_t)(cfg.workgroup / 64) * RAY_LDS_BYTES;   // ray prefetch slots
     static const size_t extra = getenv("PT_EXTRA_LDS") ? (size_t)atol(getenv("PT_EXTRA_LDS")) : 0;   // occupancy experiments
     return prim + queue + mats + scan + extra;
 }
