@@ -829,11 +829,12 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
     const bool last = (bounce == p.depth - 1);
     // Up to MAXSLOT consecutive iterations are in flight in one launch sequence; a ray carries its iteration
     // slot in the top bits of its pixel word.  The per-(iteration, bounce) stream keys are wave-uniform.
-    uint32_t key_cam[MAXSLOT], key_bounce[MAXSLOT];
-#pragma unroll
-    for (int k = 0; k < MAXSLOT; ++k) {
-        key_cam[k] = stream_key(iter + (uint32_t)k, 0u, p.seed);
-        key_bounce[k] = stream_key(iter + (uint32_t)k, (uint32_t)bounce + 1u, p.seed);
+    // The per-(iteration, bounce) stream keys sit in an LDS table indexed by the slot: one ds_read per ray instead of a
+    // compare/select chain over the slots (v_cmp / v_cndmask issue at half rate).
+    __shared__ uint32_t s_key[MAXSLOT], s_key_cam[MAXSLOT];
+    if (tid < MAXSLOT) {
+        s_key[tid] = stream_key(iter + (uint32_t)tid, (uint32_t)bounce + 1u, p.seed);
+        if (FIRST) s_key_cam[tid] = stream_key(iter + (uint32_t)tid, 0u, p.seed);
     }
     const uint32_t npix = (uint32_t)p.npix;
 
@@ -915,17 +916,19 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
         if (FIRST) {
             if (valid) {
                 // raycastFromCameraKernel: jittered pinhole ray through tile-local pixel pl of iteration slot
-                uint32_t slot = 0;
+                // 64 consecutive ray indices meet at most one slot boundary: the slot of the chunk's first ray on the
+                // scalar unit, one compare per lane for the step
+                const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(i - (uint32_t)lane));
+                uint32_t slot_lo = 0;
 #pragma unroll
-                for (uint32_t k = 1; k < (uint32_t)MAXSLOT; ++k) slot += (i >= k * npix) ? 1u : 0u;
+                for (uint32_t k = 1; k < (uint32_t)MAXSLOT; ++k) slot_lo += (base >= k * npix) ? 1u : 0u;
+                const uint32_t slot = slot_lo + ((i >= (slot_lo + 1u) * npix) ? 1u : 0u);
                 const uint32_t pl = i - slot * npix;
                 pix = pl | (slot << SLOT_SHIFT);
                 const uint32_t gp = globalPixel(p, pl);
                 const uint32_t x = pl % (uint32_t)p.W;
                 const uint32_t y = gp / (uint32_t)p.W;
-                uint32_t kc = key_cam[0];
-#pragma unroll
-                for (uint32_t k = 1; k < (uint32_t)MAXSLOT; ++k) kc = (slot == k) ? key_cam[k] : kc;
+                const uint32_t kc = s_key_cam[slot];
                 uint32_t s = minstd_seed(wang_hash(gp ^ kc));
                 s = minstd_next(s);
                 const float jx = u01_of(s);
@@ -994,9 +997,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
                 } else if (!last || NEE) {
                     // calculateBSDF: pick the lobe, build the next ray
                     const uint32_t slot = NEE ? ((pix >> SLOT_SHIFT) & (uint32_t)(MAXSLOT - 1)) : (pix >> SLOT_SHIFT);
-                    uint32_t kb = key_bounce[0];
-#pragma unroll
-                    for (uint32_t k = 1; k < (uint32_t)MAXSLOT; ++k) kb = (slot == k) ? key_bounce[k] : kb;
+                    const uint32_t kb = s_key[slot];
                     uint32_t s = minstd_seed(wang_hash(globalPixel(p, pix & PIX_MASK) ^ kb));
                     s = minstd_next(s);
                     const float u_select = u01_of(s);
