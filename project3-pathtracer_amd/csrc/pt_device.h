@@ -59,25 +59,27 @@ __device__ __forceinline__ float rcp_core(float d)
     const float e1 = __builtin_fmaf(-d, r1, 1.0f);
     return __builtin_fmaf(e1, r1, r1);
 }
+// The wave-uniform range tests are written with the compare builtins, whose result IS the lane mask (v_cmp into an
+// SGPR pair): a ballot of a bool built from several compares costs an extra v_cndmask + v_cmp per test.
+enum { FCMP_OGE = 3, FCMP_OLE = 5, FCMP_UGE = 11, FCMP_ULT = 12, ICMP_UGE = 35 };     // llvm::CmpInst predicates
 __device__ __forceinline__ float sqrt_rn(float x)                      // == sqrtf(x) for every x
 {
-    const bool ok = x >= 0x1p-96f;                                     // false for tiny, zero, negative, NaN
-    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) return sqrt_core(x);
+    // outside the range: tiny, zero, negative, NaN ("unordered or less than")
+    if (__builtin_amdgcn_fcmpf(x, 0x1p-96f, FCMP_ULT) == 0ull) return sqrt_core(x);
     return sqrtf(x);
 }
 __device__ __forceinline__ float rcp_rn(float x)                       // == 1.0f / x for every x
 {
     const float ax = fabsf(x);
-    const bool ok = ax >= 0x1p-126f && ax < 0x1p126f;
-    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) return rcp_core(x);
+    if ((__builtin_amdgcn_fcmpf(ax, 0x1p-126f, FCMP_ULT) | __builtin_amdgcn_fcmpf(ax, 0x1p126f, FCMP_UGE)) == 0ull) return rcp_core(x);
     return 1.0f / x;
 }
 __device__ __forceinline__ float rsqrt_rn(float s)                     // == 1.0f / sqrtf(s) for every s
 {
     // 2^-96 <= s < +inf (then sqrt(s) is in rcp_core's range), as one unsigned compare on the bit pattern:
     // negative numbers and NaNs wrap around to the top of the range and fail it
-    const bool ok = (__float_as_uint(s) - 0x0F800000u) < (0x7F800000u - 0x0F800000u);
-    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) return rcp_core(sqrt_core(s));
+    if (__builtin_amdgcn_uicmp(__float_as_uint(s) - 0x0F800000u, 0x7F800000u - 0x0F800000u, ICMP_UGE) == 0ull)
+        return rcp_core(sqrt_core(s));
     return 1.0f / sqrtf(s);
 }
 
@@ -225,8 +227,8 @@ __device__ __forceinline__ bool candidateT(uint32_t type, const float *inv, f3 o
     // component -- excluded here -- or a non-finite ray.
     {
         const float ax = fabsf(rd.x), ay = fabsf(rd.y), az = fabsf(rd.z);
-        const bool ok = fminf(fminf(ax, ay), az) >= 0x1p-126f && fmaxf(fmaxf(ax, ay), az) < 0x1p126f;
-        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
+        if ((__builtin_amdgcn_fcmpf(fminf(fminf(ax, ay), az), 0x1p-126f, FCMP_ULT) |
+             __builtin_amdgcn_fcmpf(fmaxf(fmaxf(ax, ay), az), 0x1p126f, FCMP_UGE)) == 0ull) {
             const float ix = rcp_core(rd.x), iy = rcp_core(rd.y), iz = rcp_core(rd.z);
             const float x0 = (-0.5f - ro.x) * ix, x1 = (0.5f - ro.x) * ix;
             const float y0 = (-0.5f - ro.y) * iy, y1 = (0.5f - ro.y) * iy;

@@ -121,7 +121,7 @@ __device__ __forceinline__ bool waveMissesBoxFromEye(const float *box_eye, int g
     const float z0 = __uint_as_float(q[2]) * inv.z, z1 = __uint_as_float(q[6]) * inv.z;
     const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
     const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-    return __ballot(valid && tn <= tf) == 0ull;
+    return (__builtin_amdgcn_fcmpf(tn, tf, FCMP_OLE) & __ballot(valid)) == 0ull;
 }
 __device__ __forceinline__ f3 approxInverse(f3 d)
 {
@@ -463,6 +463,7 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const Prim *s_p
     q.org[lane] = make_float4(o.x, o.y, o.z, 0.0f);
     q.dir[lane] = make_float4(d.x, d.y, d.z, 0.0f);
     uint32_t head[2] = {0u, 0u}, tail[2] = {0u, 0u};        // wave-uniform
+    const uint64_t vmask = __ballot(valid);
     const f3 dinv = approxInverse(d);
     // slab distances as fma(plane, 1/d, -o/d): one instruction per plane; against (plane - o)/d this moves a plane by
     // less than 1.2e-6 |o|, far inside the boxes' padding
@@ -480,9 +481,10 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const Prim *s_p
         const float z0 = __builtin_fmaf(lo.z, dinv.z, oinv.z), z1 = __builtin_fmaf(hi.z, dinv.z, oinv.z);
         const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
         const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-        const bool pass = valid && tn <= tf;
-        const uint64_t mask = __ballot(pass);
+        // the compare's lane mask straight from v_cmp, and back into a predicate without VALU work
+        const uint64_t mask = __builtin_amdgcn_fcmpf(tn, tf, FCMP_OLE) & vmask;
         if (mask == 0ull) continue;
+        const bool pass = __builtin_amdgcn_inverse_ballot_w64(mask);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         if (type == 0u) {                                    // wave-uniform
             if (pass) q.q[0][(tail[0] + rank) & (QCAP - 1u)] = lane | ((uint32_t)g << 8);
