@@ -253,6 +253,14 @@ int configure(pt_ctx *c)
     k.row_begin = r0;
     k.npix = npix;
     k.pix_offset = (uint32_t)r0 * (uint32_t)W;
+    {
+        // division by the frame width as multiply + shift: s = 29 + ceil(log2 W), m = ceil(2^s / W) < 2^30, and
+        // m*W - 2^s < W <= 2^(s-29), so the quotient is exact for every index < 2^29 (the frame has < 2^29 pixels)
+        uint32_t lg = 0;
+        while ((1ull << lg) < (unsigned long long)W) ++lg;
+        k.w_shift = 29u + lg;
+        k.w_magic = (uint32_t)(((1ull << k.w_shift) + (unsigned long long)W - 1ull) / (unsigned long long)W);
+    }
     if (o.strip_rows > 0) {
         k.strip_rows = (uint32_t)o.strip_rows; k.strip_world = (uint32_t)o.strip_world; k.strip_rank = (uint32_t)o.strip_rank;
         k.strip_span = (uint32_t)W * (uint32_t)o.strip_rows;

@@ -75,6 +75,8 @@ struct KParams {
     uint32_t strip_rows, strip_world, strip_rank;
     uint32_t strip_magic;  // j = (pl * strip_magic) >> strip_shift, exact for pl < 2^28
     uint32_t strip_shift;
+    uint32_t w_magic;      // y = (global pixel * w_magic) >> w_shift, exact for every pixel index of the frame (< 2^29)
+    uint32_t w_shift;
     int absorption;        // 1 = Beer-Lambert absorption inside refractive objects (material planes M_AR..M_AB)
     int nlights;           // direct lighting: emissive primitives (0 = feature off), indices in `lights`
     const int *lights;

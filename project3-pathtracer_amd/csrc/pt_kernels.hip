@@ -928,8 +928,8 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
                 const uint32_t pl = i - slot * npix;
                 pix = pl | (slot << SLOT_SHIFT);
                 const uint32_t gp = globalPixel(p, pl);
-                const uint32_t x = pl % (uint32_t)p.W;
-                const uint32_t y = gp / (uint32_t)p.W;
+                const uint32_t y = (uint32_t)(((unsigned long long)gp * p.w_magic) >> p.w_shift);   // gp / W
+                const uint32_t x = gp - y * (uint32_t)p.W;
                 const uint32_t kc = s_key_cam[slot];
                 uint32_t s = minstd_seed(wang_hash(gp ^ kc));
                 s = minstd_next(s);
