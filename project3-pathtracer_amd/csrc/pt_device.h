@@ -151,7 +151,8 @@ __device__ __forceinline__ uint32_t minstd_next(uint32_t x)
     const uint32_t m = 2147483647u;            // 48271*x mod (2^31-1) by Mersenne folding == Schrage's result
     uint64_t p = (uint64_t)x * 48271u;
     uint32_t r = (uint32_t)(p & m) + (uint32_t)(p >> 31);
-    return r >= m ? r - m : r;
+    const uint32_t w = r - m;                  // r < 2m: the reduced value is the smaller of r and r - m as unsigned
+    return w < r ? w : r;                      // (v_min_u32 instead of a compare + select)
 }
 __device__ __forceinline__ float u01_of(uint32_t x) { return (float)(x - 1u) / 2147483648.0f; }
 
@@ -308,8 +309,11 @@ __device__ __forceinline__ f3 randomDirectionInHemisphere(f3 normal, float xi1, 
     float over = sqrt_rn(1 - up * up);
     float around = (float)((double)xi2 * 6.2831853071795864769252867665590057683943);
     f3 notNormal;
-    if ((double)fabsf(normal.x) < 0.5773502691896257645091487805019574556476) notNormal = mk(1, 0, 0);
-    else if ((double)fabsf(normal.y) < 0.5773502691896257645091487805019574556476) notNormal = mk(0, 1, 0);
+    // ref: abs(normal.x) < SQRT_OF_ONE_THIRD with the double constant (src/interactions.h:68,73).  For a float f,
+    // (double)f < 0.57735026918962576... holds exactly when f < 0.5773503184318542f, the smallest float above the
+    // constant (float(constant) = 0.5773502588272095 lies below it): same decision, no double conversion / compare.
+    if (fabsf(normal.x) < 0.5773503184318542f) notNormal = mk(1, 0, 0);
+    else if (fabsf(normal.y) < 0.5773503184318542f) notNormal = mk(0, 1, 0);
     else notNormal = mk(0, 0, 1);
     f3 p1 = normalize(cross(normal, notNormal));
     f3 p2 = normalize(cross(normal, p1));

@@ -456,8 +456,8 @@ __device__ __forceinline__ void pairBatch(const KParams &p, const Prim *s_prims,
 
 // Must be entered by all 64 lanes of the wave (lanes without a ray pass valid = false).
 template <bool FIRST>
-__device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const Prim *s_prims, const PairQueue q, f3 o, f3 d, bool valid,
-                                               uint32_t lane)
+__device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const Prim *s_prims, const float4 *s_boxes, const PairQueue q,
+                                               f3 o, f3 d, bool valid, uint32_t lane)
 {
     q.key[lane] = KEY_NONE;
     q.org[lane] = make_float4(o.x, o.y, o.z, 0.0f);
@@ -472,10 +472,10 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const Prim *s_p
         const_u32_ptr hp = (const_u32_ptr)(uintptr_t)(p.prims + g);
         const uint32_t type = hp[0];
         if (type > 1u) continue;                             // MESH: never has geometry
-        // padded world box of the primitive against this lane's ray (camera rays: box relative to the shared eye)
-        const_u32_ptr bq = (const_u32_ptr)(uintptr_t)((FIRST ? p.box_eye : p.box_world) + 8 * g);
-        const f3 lo = mk(__uint_as_float(bq[0]), __uint_as_float(bq[1]), __uint_as_float(bq[2]));
-        const f3 hi = mk(__uint_as_float(bq[4]), __uint_as_float(bq[5]), __uint_as_float(bq[6]));
+        // padded world box of the primitive against this lane's ray (camera rays: box relative to the shared eye), through
+        // an LDS broadcast read: VGPR operands keep the six fma at the full VALU rate (SGPR operands halve it)
+        const float4 lo4 = s_boxes[2 * g], hi4 = s_boxes[2 * g + 1];
+        const f3 lo = mk(lo4.x, lo4.y, lo4.z), hi = mk(hi4.x, hi4.y, hi4.z);
         const float x0 = __builtin_fmaf(lo.x, dinv.x, oinv.x), x1 = __builtin_fmaf(hi.x, dinv.x, oinv.x);
         const float y0 = __builtin_fmaf(lo.y, dinv.y, oinv.y), y1 = __builtin_fmaf(hi.y, dinv.y, oinv.y);
         const float z0 = __builtin_fmaf(lo.z, dinv.z, oinv.z), z1 = __builtin_fmaf(hi.z, dinv.z, oinv.z);
@@ -737,7 +737,7 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const Prim *s_prims,
         pq.dir = reinterpret_cast<float4 *>(b + 2 * QCAP * 4 + 64 * 8 + 2 * 64 * 16);
         pq.dbg = p.st->dbg;
         if (GEOM == GEOM_WALK_PAIR) return nearestHitWalkPairs<FIRST>(p, p.prims, s_nodes, pq, o, d, want, lane);
-        return nearestHitPairs<FIRST>(p, s_prims, pq, o, d, want, lane);
+        return nearestHitPairs<FIRST>(p, s_prims, s_nodes, pq, o, d, want, lane);
     }
     Hit h;
     h.any = false;
@@ -780,7 +780,9 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
     Prim *s_prims = reinterpret_cast<Prim *>(smem);
     const int prim_bytes = PRIMS_IN_LDS ? p.nG * (int)sizeof(Prim) : 0;
     const float4 *s_nodes = reinterpret_cast<const float4 *>(smem + prim_bytes);
-    const int node_bytes = (GEOM == GEOM_BVH || GEOM == GEOM_WALK_PAIR) ? p.nnodes * (int)sizeof(BvhNode) : 0;
+    // pair queue: the same region holds the primitives' padded boxes (2 float4 each; relative to the eye for camera rays)
+    const int node_bytes = (GEOM == GEOM_BVH || GEOM == GEOM_WALK_PAIR) ? p.nnodes * (int)sizeof(BvhNode)
+                                                                        : (GEOM == GEOM_PAIR ? p.nG * 32 * (NEE ? 2 : 1) : 0);
     unsigned char *s_queue = smem + prim_bytes + node_bytes;
     constexpr int WAVE_LDS = (GEOM == GEOM_QUEUE) ? (int)WAVE_QUEUE_BYTES
                              : ((GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR) ? (int)PAIR_QUEUE_BYTES : 0);
@@ -813,6 +815,15 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
         const uint4 *src = reinterpret_cast<const uint4 *>(p.prims);
         uint4 *dst = reinterpret_cast<uint4 *>(s_prims);
         for (int k = tid; k < p.nG * 8; k += WG) dst[k] = src[k];
+    }
+    if (GEOM == GEOM_PAIR) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(FIRST ? p.box_eye : p.box_world);
+        uint4 *dst = reinterpret_cast<uint4 *>(smem + prim_bytes);
+        for (int k = tid; k < p.nG * 2; k += WG) dst[k] = src[k];
+        if (NEE) {                                           // shadow rays start anywhere: world boxes, second half
+            const uint4 *srcw = reinterpret_cast<const uint4 *>(p.box_world);
+            for (int k = tid; k < p.nG * 2; k += WG) dst[p.nG * 2 + k] = srcw[k];
+        }
     }
     if (GEOM == GEOM_BVH || GEOM == GEOM_WALK_PAIR) {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.bvh);
@@ -1108,7 +1119,8 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
             const uint64_t wmask = __ballot(want_shadow);
             if (wmask != 0ull) {                              // wave-uniform
                 shadow_count += (uint32_t)__popcll(wmask);
-                const Hit hs = nearestHit<GEOM, false>(p, s_prims, s_nodes, wq, so, sd, want_shadow, (uint32_t)lane);
+                const Hit hs = nearestHit<GEOM, false>(p, s_prims, (GEOM == GEOM_PAIR) ? s_nodes + 2 * p.nG : s_nodes, wq, so, sd,
+                                                       want_shadow, (uint32_t)lane);
                 if (want_shadow && hs.any && hs.prim == lprim) {
                     const float tol = 1e-3f * ((ldist > 1.0f) ? ldist : 1.0f);
                     if (fabsf(hs.t - ldist) <= tol) L = L + Ld;          // the sampled point itself is what the ray reached
@@ -1383,6 +1395,7 @@ size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg)
     size_t queue = (size_t)(cfg.workgroup / 64) * (cfg.geom == GEOM_QUEUE ? WAVE_QUEUE_BYTES
                                                    : ((cfg.geom == GEOM_PAIR || cfg.geom == GEOM_WALK_PAIR) ? PAIR_QUEUE_BYTES : 0));
     if (cfg.geom == GEOM_BVH || cfg.geom == GEOM_WALK_PAIR) prim += (size_t)p.nnodes * sizeof(BvhNode);
+    if (cfg.geom == GEOM_PAIR) prim += (size_t)p.nG * 32 * (cfg.nee ? 2 : 1);
     size_t mats = (size_t)((p.nM * M_PLANES + 3) & ~3) * sizeof(float);
     size_t scan = (size_t)((2 * (cfg.workgroup / 64) + 2 + 3) & ~3) * sizeof(uint32_t);
     if (PT_RAY_PREFETCH && cfg.geom == GEOM_PAIR && cfg.compact != 0) scan += (size_t)(cfg.workgroup / 64) * RAY_LDS_BYTES;   // ray prefetch slots
