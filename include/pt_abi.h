@@ -238,6 +238,9 @@ int  pt_multi_get_stats(pt_multi *m, pt_stats *out);                /* sums over
  *      buffer (x,y) -> picture (W-1-x, y), gamma 1.0, clamp(v*255, 0, 255) truncation ---- */
 int  pt_image_to_rgb8(const float *host_rgb, int width, int height, int flip_x, unsigned char *rgb8_out);
 int  pt_save_image_bmp(const char *path, const float *host_rgb, int width, int height, int flip_x);
+int  pt_save_image_png(const char *path, const float *host_rgb, int width, int height, int flip_x);   /* 8-bit RGB, stored deflate */
+int  pt_save_image(const char *path, const float *host_rgb, int width, int height, int flip_x);       /* "...bmp" -> BMP, else PNG
+                                                                                                         (ref: src/image.cpp:68-87) */
 
 #ifdef __cplusplus
 }

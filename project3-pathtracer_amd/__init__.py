@@ -158,6 +158,8 @@ def lib():
         "pt_scene_get_frame": (i, [vp, i, P(StaticGeom), P(Material), P(CameraData)]),
         "pt_camera_set_resolution": (i, [P(CameraData), i, i]),
         "pt_image_to_rgb8": (i, [vp, i, i, i, vp]),
+        "pt_save_image_png": (i, [cp, vp, i, i, i]),
+        "pt_save_image": (i, [cp, vp, i, i, i]),
         "pt_save_image_bmp": (i, [cp, vp, i, i, i]),
     }
     for name, (res, args) in sig.items():

@@ -97,10 +97,10 @@ bool runCuda()
         out << targetFrame;
         const string s = out.str();
         replaceString(filename, ".bmp", "." + s + ".bmp");
-        replaceString(filename, ".png", "." + s + ".bmp");     // PNG output is not built: BMP is written instead
+        replaceString(filename, ".png", "." + s + ".png");
         if (!outDir.empty()) filename = outDir + "/" + filename;
         const int W = (int)renderCam->resolution.x, H = (int)renderCam->resolution.y;
-        if (pt_save_image_bmp(filename.c_str(), reinterpret_cast<float *>(renderCam->image), W, H, 1) != PT_OK)
+        if (pt_save_image(filename.c_str(), reinterpret_cast<float *>(renderCam->image), W, H, 1) != PT_OK)
             cout << "ERROR: cannot write " << filename << endl;
         else
             cout << "Saved frame " << s << " to " << filename << endl;

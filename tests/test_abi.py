@@ -188,3 +188,43 @@ def test_animation_frames_product_loader_equals_oracle(pkg, frame):
 def test_animation_frame_out_of_range(pkg):
     with pytest.raises(pkg.PtError):
         pkg.SceneFile(os.path.join(SCENES, "sampleScene_anim.txt"), 0, frame=3)
+
+
+def read_png_rgb8(path):
+    """Minimal PNG reader (8-bit RGB, filter 0 rows): enough to check the writer against zlib and the CRCs."""
+    import struct
+    import zlib
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, W, H = 8, b"", 0, 0
+    while pos < len(raw):
+        n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+        data = raw[pos + 8:pos + 8 + n]
+        crc, = struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])
+        assert zlib.crc32(typ + data) & 0xFFFFFFFF == crc, typ
+        if typ == b"IHDR":
+            W, H, depth, ctype, comp, filt, inter = struct.unpack(">IIBBBBB", data)
+            assert (depth, ctype, comp, filt, inter) == (8, 2, 0, 0, 0)
+        elif typ == b"IDAT":
+            idat += data
+        pos += 12 + n
+    rows = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(H, 1 + 3 * W)      # checks Adler-32 too
+    assert (rows[:, 0] == 0).all()
+    return rows[:, 1:].reshape(H, W, 3)
+
+
+@pytest.mark.parametrize("w,h", [(5, 3), (200, 150)])            # the second needs several stored deflate blocks
+def test_png_write_out(pkg, tmp_path, w, h):
+    """PNG container (ref: src/image.cpp:86): same pixels as the BMP path -- x flip, clamp(v*255) truncation -- rows
+    top-down; pt_save_image picks the container from the name like the reference (…bmp -> BMP, else PNG)."""
+    rng = np.random.default_rng(3)
+    img = rng.uniform(-0.2, 1.3, (h, w, 3)).astype(np.float32)
+    want = np.zeros((h, w, 3), dtype=np.uint8)
+    assert pkg.lib().pt_image_to_rgb8(img.ctypes.data, w, h, 1, want.ctypes.data) == 0
+    path = str(tmp_path / "t.0.png")
+    assert pkg.lib().pt_save_image_png(path.encode(), img.ctypes.data, w, h, 1) == 0
+    assert np.array_equal(read_png_rgb8(path), want)
+    p2, p3 = str(tmp_path / "a.png"), str(tmp_path / "a.bmp")
+    assert pkg.lib().pt_save_image(p2.encode(), img.ctypes.data, w, h, 1) == 0
+    assert pkg.lib().pt_save_image(p3.encode(), img.ctypes.data, w, h, 1) == 0
+    assert open(p2, "rb").read(4) == b"\x89PNG" and open(p3, "rb").read(2) == b"BM"

@@ -113,3 +113,23 @@ def test_headless_direct_lighting(tmp_path):
     ref, _ = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, depth, iters=iters, direct_light=1)
     q = np.clip(ref * np.float32(255.0), 0, 255).astype(np.uint8)[:, ::-1, :]
     assert np.array_equal(got, q)
+
+
+def test_headless_writes_png_when_the_scene_asks_for_one(tmp_path):
+    """FILE name.png in the scene file -> "<name>.<frame>.png" (ref: src/main.cpp:138, src/image.cpp:86)."""
+    from test_abi import read_png_rgb8
+    pkg = load_package()
+    W, H, depth, iters = 64, 40, 3, 4
+    text = open(os.path.join(ROOT, "scenes", "sampleScene_spec.txt")).read().replace("FILE spec.bmp", "FILE shot.png")
+    scene = os.path.join(tmp_path, "scene_png.txt")
+    open(scene, "w").write(text)
+    env = dict(os.environ, PT_DEPTH=str(depth))
+    res = subprocess.run([pkg.HEADLESS_PATH, f"scene={scene}", "frame=0", f"res={W}x{H}", f"iterations={iters}", f"out={tmp_path}"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    got = read_png_rgb8(os.path.join(tmp_path, "shot.0.png"))
+    sc = O.LoadedScene(scene)
+    sc.set_resolution(W, H)
+    ref, _ = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, depth, iters=iters)
+    q = np.clip(ref * np.float32(255.0), 0, 255).astype(np.uint8)[:, ::-1, :]
+    assert np.array_equal(got, q)
