@@ -640,3 +640,21 @@ def test_very_large_primitive_lists(pkg, n_prims, paths):
             img = r.download_image()
             st = r.stats()
         check(img, ref, [int(x) for x in st.live_in[:depth]], [int(x) for x in live], f"{n_prims} primitives geom_path={gp}")
+
+
+# ---------------------------------------------------------------- committed golden fixtures
+def _golden_cases():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "render_checksums.json")))
+
+
+@pytest.mark.parametrize("name", sorted(_golden_cases()))
+def test_gpu_image_hashes_to_the_committed_golden(pkg, name):
+    """The HIP path against the committed fixtures themselves (tests/golden/render_checksums.json: SHA-256 of the fp32
+    image + live-ray counts, generated by oracle/make_render_golden.py), not only against the oracle run at test time."""
+    import hashlib
+    c = _golden_cases()[name]
+    img, live, _ = gpu_render(pkg, c["scene"], c["width"], c["height"], c["depth"], iters=c["iterations"], rotat=c["rotat"],
+                              **c["options"])
+    assert live == c["live_in"]
+    assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == c["sha256"]

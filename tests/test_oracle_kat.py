@@ -8,7 +8,9 @@ Pins the oracle (oracle/pt_oracle.c) to
 No GPU needed.
 """
 import ctypes as C
+import json
 import math
+import os
 
 import numpy as np
 import pytest
@@ -254,3 +256,19 @@ def test_pbo_conversion(oracle):
     L.o_sendImageToPBO(out.ctypes.data, 3, img.ctypes.data)
     want = np.array([[0, 127, 255, 0], [255, 254, 0, 0], [63, 1, 254, 0]], dtype=np.uint8)
     assert (out == want).all()
+
+
+def test_render_checksums():
+    """The canonical render semantics are pinned across rounds: the oracle's images for a handful of small
+    configurations hash to the committed values (tests/golden/render_checksums.json, oracle/make_render_golden.py)."""
+    import hashlib
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_render_golden", os.path.join(root, "oracle", "make_render_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    want = json.load(open(os.path.join(root, "tests", "golden", "render_checksums.json")))
+    assert sorted(want) == sorted(c[0] for c in gen.CASES)
+    for case in gen.CASES:
+        got = gen.run(case)
+        assert got["sha256"] == want[case[0]]["sha256"] and got["live_in"] == want[case[0]]["live_in"], case[0]
