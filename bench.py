@@ -83,7 +83,13 @@ def cpu_baseline(args, scene_path, rotat):
                        rr_start=args.rr_start, nthreads=cores, direct_light=1 if args.direct_light else 0)
     dt = time.perf_counter() - t0
     rb = int(live.sum())
+    # per-core figure: the quarter-resolution frame on one thread
+    t1 = time.perf_counter()
+    _, live1 = O.render(sc_small.geoms, sc_small.n_objects, sc_small.mats, sc_small.n_materials, sc_small.camera,
+                        args.depth, iters=1, rr_start=args.rr_start, nthreads=1, direct_light=1 if args.direct_light else 0)
+    dt1 = time.perf_counter() - t1
     return {"value": rb / dt / 1e6, "unit": "Mray-bounces/s", "cores": cores, "kind": "port",
+            "single_thread": int(live1.sum()) / dt1 / 1e6,
             "sample": f"{args.width}x{args.height} x {spp} spp x {args.depth} bounces of the same scene "
                       f"({rb} ray-bounces in {dt:.2f} s, oracle/pt_oracle.c, {cores} threads)",
             "ms_per_frame": dt / spp * 1e3}
