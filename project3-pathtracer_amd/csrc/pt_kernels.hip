@@ -8,12 +8,13 @@
 //   k_iter_*               iteration bookkeeping (live-ray counters, stats) kept on the device so that one
 //                          hipGraph can be replayed per iteration
 //
-// Execution model (wave64): one lane = one live ray; the primitive loop is wave-uniform, so primitive
-// records travel through the scalar unit (s_load -> SGPR operands of the VALU ops) or one LDS broadcast read.
-// Rays live in SoA pools (pt_internal.h RayPool); survivors of a bounce are written densely into the other
-// pool: wave ballot + v_mbcnt prefix, an LDS scan over the workgroup's waves, one global atomic per
-// workgroup.  Results do not depend on the order rays land in the pool because every RNG stream is keyed on
-// (global pixel, iteration, bounce).
+// Execution model (wave64): one lane = one live ray, up to 8 iterations in flight per launch.  The nearest-hit
+// search comes in six interchangeable forms (GEOM_*, below); the default ones first run a cheap per-lane box
+// pre-test and then do the exact intersection work on full 64-wide batches of (ray, primitive) pairs drawn
+// from a wave-private LDS queue.  Rays live in SoA pools (pt_internal.h RayPool); survivors of a bounce are
+// written densely into the other pool: wave ballot + v_mbcnt prefix and ONE atomic per wave on one of 8
+// sharded counters (no workgroup barrier).  Results do not depend on the order rays land in the pool because
+// every RNG stream is keyed on (global pixel, iteration, bounce).  DESIGN.md section 5 has the measurements.
 //
 // Compile with -ffp-contract=off (see pt_device.h).
 #include <stdlib.h>
