@@ -213,7 +213,7 @@ def main():
         npix = W * Hband
         alg_bytes = pkg.algorithmic_bytes(npix, live_in, args.steps)      # this rank, the timed K steps
         # dominant kernel: k_bounce, one HIP event pair per launch on the render stream (a few extra steps)
-        prof_steps = 8
+        prof_steps = args.batch or 16          # one full batch: the same launch shape as the timed region
         r.reset_stats()
         bounce_ms = r.render_profiled(first + args.steps, prof_steps)
         pst = r.stats()
@@ -248,7 +248,7 @@ def main():
                             f"{args.depth} bounces, diffuse+specular, rotat={args.rotat}, rr_start={args.rr_start}",
                 "scene": args.scene, "width": W, "height": Hfull, "depth": args.depth, "spp": args.steps,
                 "rotat_units": args.rotat, "primitives": sc.n_objects, "materials": sc.n_materials,
-                "compaction": 0 if args.no_compaction else args.compaction, "iteration_batch": args.batch or 8, "hip_graph": not args.no_graph, "direct_light": bool(args.direct_light),
+                "compaction": 0 if args.no_compaction else args.compaction, "iteration_batch": args.batch or 16, "hip_graph": not args.no_graph, "direct_light": bool(args.direct_light),
                 "parallelism": (f"pixel-strips x{world}" if strips else f"pixel-bands x{world}") + (", 1 RCCL gather" if world > 1 else ""),
             },
             "ray_bounces": int(rb_total),

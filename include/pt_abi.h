@@ -92,7 +92,7 @@ typedef struct pt_options {
     int row_begin;        /* tile rendered by this context: rows [row_begin, row_end) of the frame; */
     int row_end;          /*   0,0 = the whole frame.  RNG streams are keyed on the global pixel index. */
     int use_graph;        /* 1 = replay one captured hipGraph per launch sequence (default), 0 = eager launches */
-    int batch;            /* iterations rendered concurrently by one launch sequence, 1..8 (default 0 = library choice 8);
+    int batch;            /* iterations rendered concurrently by one launch sequence, 1..16 (default 0 = library choice 16);
                              their samples are folded into the running mean in iteration order, so the image does not
                              depend on it */
     int direct_light;     /* 1 = sample the lights explicitly at every diffuse vertex (one shadow ray; the reference's

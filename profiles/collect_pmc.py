@@ -69,8 +69,8 @@ def short(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", default="r01")
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=8)      # one full batch, so every counted launch is a full-batch launch
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=16)     # one full batch, so every counted launch is a full-batch launch
     ap.add_argument("--passes", default="trace,sq1,sq2,sq3,fetch,write,tcc")
     ap.add_argument("bench_args", nargs="*")
     a = ap.parse_args()

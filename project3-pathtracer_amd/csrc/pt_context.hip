@@ -493,7 +493,7 @@ int configure(pt_ctx *c)
     // amortises the per-launch fixed cost (launch, LDS staging, ramp, tail) over `batch` samples per pixel
     int batch = o.batch == 0 ? pt::PT_MAX_BATCH : o.batch;
     while (batch > 1 && (long long)npix * batch > (1LL << 28)) --batch;
-    if (npix >= (1 << 28)) return fail(PT_ERR_INVALID, "tile of %d pixels too large (pixel index must fit 28 bits)", npix);
+    if (npix >= (1 << 27)) return fail(PT_ERR_INVALID, "tile of %d pixels too large (pixel index must fit 27 bits)", npix);
     c->batch = batch;
     k.nslot = batch;
     const long long nrays = (long long)npix * batch;
@@ -806,8 +806,8 @@ int pt_render(pt_ctx *c, int iter_first, int iter_count)
 
     if (c->timers.size() >= 1024) { rc = fold_timers(c); if (rc != PT_OK) return rc; }
     hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventCreateWithFlags(&e0, hipEventDisableSystemFence));
+    HIP_TRY(hipEventCreateWithFlags(&e1, hipEventDisableSystemFence));
     c->timers.emplace_back(e0, e1);
     HIP_TRY(hipEventRecord(e0, s));
 
@@ -847,7 +847,9 @@ int pt_render_profiled(pt_ctx *c, int iter_first, int iter_count, double *bounce
     if (iter_count == 0) return PT_OK;
     hipStream_t s = c->stream;
     std::vector<hipEvent_t> ev((size_t)2 * (size_t)depth);
-    for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+    // no system-scope fence at the events: a default event makes every kernel end with an L2 write-back and start with
+    // a cold cache, which showed up as +12 % on the launches bracketed this way
+    for (auto &e : ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
     const int B = c->batch;
     HIP_TRY(pt::launch_iter_set(s, c->d_state, (uint32_t)(iter_first - B)));
     int launches = 0;

@@ -39,8 +39,8 @@ static constexpr bool DEBUG_CULL = false;
 static constexpr bool DEBUG_PAIR = false;
 static constexpr bool DEBUG_PHASE = false;       // per-wave shader-clock stamps between the phases of a chunk -> IterState::dbg
 static constexpr bool DEBUG_BVH = false;        // count node / leaf visits of the hierarchy walk into IterState::dbg
-static constexpr int MAXSLOT = 8;                 // iterations in flight per launch sequence (pt_internal.h PT_MAX_BATCH)
-static constexpr uint32_t SLOT_SHIFT = 28;        // pixel word = tile-local pixel | slot << 28
+static constexpr int MAXSLOT = 16;                // iterations in flight per launch sequence (pt_internal.h PT_MAX_BATCH)
+static constexpr uint32_t SLOT_SHIFT = 27;        // pixel word = tile-local pixel | slot << 27 | NEE mark << 31
 static constexpr uint32_t PIX_MASK = (1u << SLOT_SHIFT) - 1u;
 
 typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;

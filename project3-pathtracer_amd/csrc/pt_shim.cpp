@@ -18,7 +18,7 @@
 //                         (pt_multi_*), the bands are gathered into renderCam->image; PBO output then needs 1 device
 //   PT_STRIP_ROWS (8)     with several devices: rows per interleaved strip (device k renders strips k, k+n, ...); 0 = one
 //                         contiguous band per device
-//   PT_SHIM_BATCH (8)     iterations that may be pending inside the shim before they are rendered together
+//   PT_SHIM_BATCH (16)    iterations that may be pending inside the shim before they are rendered together
 //                         (only while nobody can observe them: no PBO, no read-back due); 1 = render every call
 //   PT_READBACK_EVERY (0) also copy the image back every N iterations (0 = only on the last one,
 //                         iterations == renderCam->iterations, which is when src/main.cpp:114-125 reads it);
@@ -44,7 +44,7 @@ struct ShimState {
     int readback_every = 0;
     int last_iteration = 0;     // the last iteration handed to this shim (rendered or pending)
     int pend_first = 0, pend_count = 0;   // iterations accepted but not enqueued yet (rendered in batches)
-    int defer = 8;              // PT_SHIM_BATCH: how many iterations may be pending; 1 = render on every call
+    int defer = 16;             // PT_SHIM_BATCH: how many iterations may be pending; 1 = render on every call
 };
 ShimState g;
 
@@ -98,7 +98,7 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
         check(pt_multi_set_options(g.ctx, &o), "pt_set_options");
         if (g.ndev > 1) check(pt_multi_set_strips(g.ctx, env_int("PT_STRIP_ROWS", 8)), "pt_multi_set_strips");
         g.readback_every = env_int("PT_READBACK_EVERY", 0);
-        g.defer = env_int("PT_SHIM_BATCH", 8);
+        g.defer = env_int("PT_SHIM_BATCH", 16);
         if (g.defer < 1) g.defer = 1;
     }
 

@@ -138,14 +138,15 @@ def test_multi_iteration_running_mean(pkg):
     assert st.iterations == 6
 
 
-@pytest.mark.parametrize("batch", [1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize("batch", [1, 2, 3, 4, 5, 8, 11, 16])
 def test_iteration_batching_is_invisible(pkg, batch):
     """1..8 iterations in flight per launch sequence; samples are folded in iteration order, so the running
     mean is the same bits, also when the iteration count is not a multiple of the batch."""
-    g, lg, st = gpu_render(pkg, "sampleScene_spec.txt", 121, 67, 5, iters=11, batch=batch, rr_start=2)
-    c, lc = cpu_render("sampleScene_spec.txt", 121, 67, 5, iters=11, rr_start=2)
+    iters = 37 if batch > 8 else 11
+    g, lg, st = gpu_render(pkg, "sampleScene_spec.txt", 121, 67, 5, iters=iters, batch=batch, rr_start=2)
+    c, lc = cpu_render("sampleScene_spec.txt", 121, 67, 5, iters=iters, rr_start=2)
     check(g, c, lg, lc, f"batch={batch}")
-    assert st.iterations == 11
+    assert st.iterations == iters
 
 
 def test_resume_from_host_image(pkg):
@@ -512,7 +513,7 @@ def test_direct_lighting_on_every_geometry_path(pkg, geom_path):
 def test_direct_lighting_batching_rr_and_large_scene(pkg):
     W, H = 64, 48
     cpu, lc, shadows = cpu_render_dl("cloud256.txt", W, H, 6, iters=5, rotat=1, rr_start=2)
-    for batch in (1, 3, 8):
+    for batch in (1, 3, 8, 16):
         gpu, lg, st = gpu_render(pkg, "cloud256.txt", W, H, 6, iters=5, rotat=1, direct_light=1, rr_start=2, batch=batch)
         check(gpu, cpu, lg, lc, f"direct lighting cloud256 batch {batch}")
         assert int(st.shadow_rays) == shadows
