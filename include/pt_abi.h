@@ -106,6 +106,8 @@ typedef struct pt_options {
     int strip_rank;       /*   strips packed in order (balances ranks when path lengths vary down the frame); row_begin =
                                row_end = 0 then.  pt_strip_local_rows / pt_strip_global_row give the mapping.  0 = off */
     int reserved[1];
+    float lens_radius;    /* > 0: thin-lens camera (depth of field): rays start on a disc of this radius around the eye and */
+    float focal_distance; /*   aim at the pinhole ray's point on the plane focal_distance along the view axis; 0 = pinhole */
 } pt_options;
 
 typedef struct pt_stats {

@@ -479,7 +479,7 @@ o_vec3 o_generateRandomNumberFromThread(o_vec2 resolution, float time, int x, in
 }
 
 /* camera basis: the part of the camera ray that does not depend on the pixel (host-side in the product) */
-typedef struct { o_vec3 eye, M, H, V; float resx, resy; } cam_basis;
+typedef struct { o_vec3 eye, M, H, V; float resx, resy; o_vec3 A, B, vn; } cam_basis;
 static cam_basis camera_basis(o_vec2 resolution, o_vec3 eye, o_vec3 view, o_vec3 up, o_vec2 fov)
 {
     cam_basis b;
@@ -493,7 +493,25 @@ static cam_basis camera_basis(o_vec2 resolution, o_vec3 eye, o_vec3 view, o_vec3
     b.H = scale3(lenV * tx, A);
     b.V = scale3(lenV * ty, B);
     b.resx = resolution.x; b.resy = resolution.y;
+    b.A = A; b.B = B; b.vn = normalize3(view);            /* unit axes of the lens plane and its normal */
     return b;
+}
+
+/* spec (depth of field): thin lens.  The pinhole ray fixes the point in focus on the plane
+ * focal_distance along the view axis; the ray starts on a disc of lens_radius around the eye in the (A, B) plane
+ * -- r = R sqrt(u1), angle 2 pi u2 with the deterministic sincos -- and aims at that point. */
+static o_ray lens_ray(const cam_basis *b, o_ray pinhole, float lens_radius, float focal_distance, float u1, float u2)
+{
+    float tf = focal_distance / dot3(pinhole.direction, b->vn);
+    o_vec3 Pf = add3(b->eye, scale3(tf, pinhole.direction));
+    float rr = lens_radius * sqrtf(u1);
+    float around = (float)((double)u2 * O_TWO_PI);
+    float sn, cs;
+    o_sincos_poly(around, &sn, &cs);
+    o_ray r;
+    r.origin = add3(b->eye, add3(scale3(rr * cs, b->A), scale3(rr * sn, b->B)));
+    r.direction = normalize3(sub3(Pf, r.origin));
+    return r;
 }
 static o_ray camera_ray(const cam_basis *b, int x, int y, float jx, float jy)
 {
@@ -579,6 +597,10 @@ static o_vec3 trace_path(const o_staticGeom *geoms, int nG, const o_material *ma
     unsigned rng; o_minstd_seed(&rng, o_stream_seed(pixel, iteration, 0u, opt->seed));
     float jx = o_u01(&rng), jy = o_u01(&rng);
     o_ray r = camera_ray(cb, x, y, jx, jy);
+    if (opt->lens_radius > 0.0f) {
+        float u1 = o_u01(&rng), u2 = o_u01(&rng);
+        r = lens_ray(cb, r, opt->lens_radius, opt->focal_distance, u1, u2);
+    }
     o_vec3 T = v3(1, 1, 1), L = v3(0, 0, 0);
     const int nee = opt->direct_light && lt && lt->n > 0;          /* explicit light sampling at diffuse vertices */
     int suppress = 0;     /* the previous vertex sampled the lights explicitly: hitting one by chance adds nothing */

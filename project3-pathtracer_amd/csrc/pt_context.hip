@@ -248,6 +248,12 @@ int configure(pt_ctx *c)
         k.H[0] = hx * A.x; k.H[1] = hx * A.y; k.H[2] = hx * A.z;
         k.V[0] = vy * B.x; k.V[1] = vy * B.y; k.V[2] = vy * B.z;
         k.resx = c->cam.resolution.x; k.resy = c->cam.resolution.y;
+        const v3 vn = normalize3(view);
+        k.A[0] = A.x; k.A[1] = A.y; k.A[2] = A.z;
+        k.B[0] = B.x; k.B[1] = B.y; k.B[2] = B.z;
+        k.vn[0] = vn.x; k.vn[1] = vn.y; k.vn[2] = vn.z;
+        k.lens_radius = o.lens_radius > 0.0f ? o.lens_radius : 0.0f;
+        k.focal_distance = o.focal_distance;
     }
     k.W = W;
     k.row_begin = r0;
@@ -608,6 +614,8 @@ void pt_default_options(pt_options *o)
     o->geom_path = 0;
     o->use_graph = 1;
     o->batch = 0;
+    o->lens_radius = 0.0f;
+    o->focal_distance = 1.0f;
 }
 
 int pt_create(int device, pt_ctx **out)
@@ -681,6 +689,8 @@ int pt_set_options(pt_ctx *c, const pt_options *o)
     if (o->compaction < 0 || o->compaction > 2) return fail(PT_ERR_INVALID, "compaction %d not 0, 1 or 2", o->compaction);
     if (o->direct_light < 0 || o->direct_light > 1) return fail(PT_ERR_INVALID, "direct_light %d not 0 or 1", o->direct_light);
     if (o->absorption < 0 || o->absorption > 1) return fail(PT_ERR_INVALID, "absorption %d not 0 or 1", o->absorption);
+    if (!(o->lens_radius >= 0.0f) || (o->lens_radius > 0.0f && !(o->focal_distance > 0.0f)))
+        return fail(PT_ERR_INVALID, "lens radius %g / focal distance %g", (double)o->lens_radius, (double)o->focal_distance);
     if (o->direct_light && o->compaction != 1) return fail(PT_ERR_INVALID, "direct_light needs compaction 1 (got %d)", o->compaction);
     c->opt = *o;
     c->dirty = true;

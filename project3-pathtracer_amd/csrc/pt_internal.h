@@ -44,6 +44,8 @@ struct KParams {
     // camera basis (host-side part of raycastFromCameraKernel)
     float eye[3], M[3], H[3], V[3];
     float resx, resy;
+    float A[3], B[3], vn[3];     // unit screen-right, screen-up and view axes (thin lens)
+    float lens_radius, focal_distance;   // lens_radius > 0: depth of field; camera rays then have their own origins
     int W;                 // frame width
     int row_begin;         // first frame row of this context's tile
     int npix;              // pixels in the tile

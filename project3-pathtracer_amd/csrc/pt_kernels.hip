@@ -818,7 +818,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
         for (int k = tid; k < p.nG * 8; k += WG) dst[k] = src[k];
     }
     if (GEOM == GEOM_PAIR) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(FIRST ? p.box_eye : p.box_world);
+        const uint4 *src = reinterpret_cast<const uint4 *>((FIRST && !(p.lens_radius > 0.0f)) ? p.box_eye : p.box_world);
         uint4 *dst = reinterpret_cast<uint4 *>(smem + prim_bytes);
         for (int k = tid; k < p.nG * 2; k += WG) dst[k] = src[k];
         if (NEE) {                                           // shadow rays start anywhere: world boxes, second half
@@ -955,6 +955,21 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
                              (1.0f - 2.0f * sy) * mk(p.V[0], p.V[1], p.V[2]);
                 o = eye;
                 d = normalize(P - eye);
+                if (p.lens_radius > 0.0f) {
+                    // thin lens (depth of field): the pinhole ray fixes the point in focus; start on the lens disc
+                    s = minstd_next(s);
+                    const float u1 = u01_of(s);
+                    s = minstd_next(s);
+                    const float u2 = u01_of(s);
+                    const float tf = p.focal_distance / dot(d, mk(p.vn[0], p.vn[1], p.vn[2]));
+                    const f3 Pf = eye + tf * d;
+                    const float rr = p.lens_radius * sqrt_rn(u1);
+                    const float around = (float)((double)u2 * 6.2831853071795864769252867665590057683943);
+                    float sn, cs;
+                    sincos_poly(around, sn, cs);
+                    o = eye + ((rr * cs) * mk(p.A[0], p.A[1], p.A[2]) + (rr * sn) * mk(p.B[0], p.B[1], p.B[2]));
+                    d = normalize(Pf - o);
+                }
             }
         } else if (PREFETCH) {
             for (;;) {                                                  // this chunk's records have landed in LDS
@@ -991,7 +1006,9 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
 
         bool alive = false;
         const unsigned long long c1 = DEBUG_PHASE ? __builtin_amdgcn_s_memtime() : 0ull;
-        const Hit h = nearestHit<GEOM, FIRST>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane);
+        // camera rays share the eye (host-side eye transforms and eye-relative boxes) unless a lens spreads their origins
+        const Hit h = (FIRST && p.lens_radius > 0.0f) ? nearestHit<GEOM, false>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane)
+                                                      : nearestHit<GEOM, FIRST>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane);
         const unsigned long long c2 = DEBUG_PHASE ? __builtin_amdgcn_s_memtime() : 0ull;
         f3 L = mk(0, 0, 0);               // radiance this vertex adds to the path's sample
         // direct lighting: the shadow ray this lane wants traced and what it is worth if the light is visible

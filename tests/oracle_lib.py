@@ -61,7 +61,7 @@ class Fresnel(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("depth", C.c_int), ("rr_start", C.c_int), ("seed", C.c_uint), ("trig_mode", C.c_int),
-                ("direct_light", C.c_int), ("absorption", C.c_int)]
+                ("direct_light", C.c_int), ("absorption", C.c_int), ("lens_radius", C.c_float), ("focal_distance", C.c_float)]
 
 
 class Scene(C.Structure):
@@ -215,7 +215,7 @@ class LoadedScene:
 
 
 def render(geoms, nG, mats, nM, cam, depth, iters=1, iter_first=1, rr_start=-1, seed=0, trig=TRIG_POLY,
-           image=None, nthreads=None, direct_light=0, shadow_out=None, absorption=0):
+           image=None, nthreads=None, direct_light=0, shadow_out=None, absorption=0, lens_radius=0.0, focal_distance=1.0):
     """Returns (image[H,W,3] float32, live_in[depth] uint64); shadow_out (a list) receives the shadow-ray count."""
     W, H = int(cam.resolution.x), int(cam.resolution.y)
     if image is None:
@@ -223,7 +223,7 @@ def render(geoms, nG, mats, nM, cam, depth, iters=1, iter_first=1, rr_start=-1, 
     else:
         image = np.ascontiguousarray(image, dtype=np.float32).copy()
     live = np.zeros(depth, dtype=np.uint64)
-    opt = Options(depth, rr_start, seed, trig, direct_light, absorption)
+    opt = Options(depth, rr_start, seed, trig, direct_light, absorption, lens_radius, focal_distance)
     if nthreads is None:
         nthreads = os.cpu_count() or 1
     shadow = C.c_ulonglong(0)

@@ -659,3 +659,37 @@ def test_gpu_image_hashes_to_the_committed_golden(pkg, name):
                               **c["options"])
     assert live == c["live_in"]
     assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == c["sha256"]
+
+
+# ---------------------------------------------------------------- depth of field
+@pytest.mark.parametrize("geom_path,extra", [(0, {}), (3, {}), (4, {}), (6, {}), (5, {"direct_light": 1}),
+                                             (0, {"strip_rows": 4, "strip_world": 2, "strip_rank": 1})])
+def test_thin_lens_camera_matches_oracle(pkg, geom_path, extra):
+    """pt_options.lens_radius / focal_distance: camera rays start on the lens disc, so the camera kernel gives up its
+    shared-eye shortcuts (host eye transforms, eye-relative boxes) -- on every geometry path, with direct lighting and
+    on a strip tile."""
+    W, H, depth, iters = 88, 66, 4, 3
+    sc = O.LoadedScene(os.path.join(SCENES, "sampleScene_spec.txt"), 1)
+    sc.set_resolution(W, H)
+    sh = []
+    cpu, lc = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, depth, iters=iters, lens_radius=0.35,
+                       focal_distance=11.5, direct_light=extra.get("direct_light", 0), shadow_out=sh)
+    gpu, lg, st = gpu_render(pkg, "sampleScene_spec.txt", W, H, depth, iters=iters, rotat=1, geom_path=geom_path,
+                             lens_radius=0.35, focal_distance=11.5, **extra)
+    if "strip_rows" in extra:
+        from project3_pathtracer_amd import sharding
+        rows = sharding.strip_global_rows(H, 2, 1, 4)
+        assert np.array_equal(gpu, cpu[rows])
+    else:
+        check(gpu, cpu, lg, [int(x) for x in lc], f"thin lens geom_path={geom_path} {extra}")
+        assert int(st.shadow_rays) == sh[0]
+    pin, _, _ = gpu_render(pkg, "sampleScene_spec.txt", W, H, depth, iters=iters, rotat=1)
+    assert "strip_rows" in extra or not np.array_equal(pin, gpu)
+
+
+def test_lens_options_are_validated(pkg):
+    with pkg.Renderer(0) as r:
+        for bad in (dict(lens_radius=-1.0), dict(lens_radius=0.5, focal_distance=0.0), dict(lens_radius=float("nan"))):
+            with pytest.raises(pkg.PtError):
+                r.set_options(**bad)
+            r.set_options(lens_radius=0.0, focal_distance=1.0)

@@ -392,3 +392,21 @@ def test_transmitted_rays_cross_scaled_objects(scale):
             nb = C.c_int(0)
             v = L.o_trace_path(geoms, 2, mats, 2, C.byref(cam), C.byref(opt), 0, 0, 1, C.byref(nb))
             assert v.tup() == want and nb.value == depth, (kind, scale, depth, v.tup(), nb.value)
+
+
+def test_thin_lens_focus():
+    """Depth of field: a small light on the plane in focus images as sharply as through the pinhole; off that plane it
+    spreads over more pixels at the same total energy (within sampling noise)."""
+    mats = (O.Material * 1)(O.make_material(color=(1, 1, 1), emittance=1.0))
+    cam = O.make_camera(64, 64, (0, 0, 10), (0, 0, -1), (0, 1, 0), 6.0)
+    geoms = (O.StaticGeom * 1)(O.make_geom(O.SPHERE, 0, (0, 0, 0), (0, 0, 0), (0.5, 0.5, 0.5)))
+
+    def lit(**kw):
+        img, _ = O.render(geoms, 1, mats, 1, cam, 1, iters=64, **kw)
+        return int((img[..., 0] > 0.02).sum()), float(img[..., 0].sum())
+
+    n_pin, e_pin = lit()
+    n_focus, e_focus = lit(lens_radius=0.4, focal_distance=10.0)
+    n_blur, e_blur = lit(lens_radius=0.4, focal_distance=5.0)
+    assert abs(n_focus - n_pin) <= 0.35 * n_pin and n_blur > 2.5 * n_pin
+    assert abs(e_focus - e_pin) <= 0.1 * e_pin and abs(e_blur - e_pin) <= 0.15 * e_pin
