@@ -24,6 +24,7 @@ CASES = [
     ("glass_absorption", "cornell_glass.txt", 1, 80, 60, 10, 2, {"absorption": 1}),
     ("direct_light", "sampleScene.txt", 1, 80, 60, 4, 2, {"direct_light": 1}),
     ("cloud256", "cloud256.txt", 1, 64, 36, 6, 1, {"seed": 5}),
+    ("thin_lens", "sampleScene_spec.txt", 1, 72, 54, 5, 2, {"lens_radius": 0.3, "focal_distance": 11.0}),
 ]
 
 
