@@ -426,7 +426,7 @@ int configure(pt_ctx *c)
         float slo[3] = {0, 0, 0}, shi[3] = {0, 0, 0};
         bool first_box = true;
         for (size_t i = 0; i < c->geoms.size(); ++i) {
-            boxes[i] = prim_bounds(c->geoms[i]);
+            boxes[i] = prim_bounds(c->geoms[i], 1.005, 1e-4);    // hit-or-miss culling: the distance pruning has its own slack
             if (c->geoms[i].type == PT_MESH) continue;
             for (int a = 0; a < 3; ++a) {
                 if (first_box || boxes[i].lo[a] < slo[a]) slo[a] = boxes[i].lo[a];
