@@ -930,13 +930,20 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
         if (FIRST) {
             if (valid) {
                 // raycastFromCameraKernel: jittered pinhole ray through tile-local pixel pl of iteration slot
-                // 64 consecutive ray indices meet at most one slot boundary: the slot of the chunk's first ray on the
-                // scalar unit, one compare per lane for the step
-                const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(i - (uint32_t)lane));
-                uint32_t slot_lo = 0;
+                // With at least 64 pixels per slot, 64 consecutive ray indices meet at most one slot boundary: the slot
+                // of the chunk's first ray on the scalar unit, one compare per lane for the step.  Tiny tiles (a chunk
+                // spans several slots) take the general count.
+                uint32_t slot = 0;
+                if (npix >= 64u) {
+                    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(i - (uint32_t)lane));
+                    uint32_t slot_lo = 0;
 #pragma unroll
-                for (uint32_t k = 1; k < (uint32_t)MAXSLOT; ++k) slot_lo += (base >= k * npix) ? 1u : 0u;
-                const uint32_t slot = slot_lo + ((i >= (slot_lo + 1u) * npix) ? 1u : 0u);
+                    for (uint32_t k = 1; k < (uint32_t)MAXSLOT; ++k) slot_lo += (base >= k * npix) ? 1u : 0u;
+                    slot = slot_lo + ((i >= (slot_lo + 1u) * npix) ? 1u : 0u);
+                } else {
+#pragma unroll
+                    for (uint32_t k = 1; k < (uint32_t)MAXSLOT; ++k) slot += (i >= k * npix) ? 1u : 0u;
+                }
                 const uint32_t pl = i - slot * npix;
                 pix = pl | (slot << SLOT_SHIFT);
                 const uint32_t gp = globalPixel(p, pl);

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Randomised differential run of the HIP path against the oracle (not collected by pytest: run by hand on a GPU box).
+
+    python tests/fuzz_gpu.py [cases=200] [seed0=0]
+
+Every case draws a random scene (tests/test_gpu_parity.py::_random_scene), camera, and a random mix of options
+(depth, Russian roulette, seed, geometry path, batch, direct lighting, absorption, thin lens, strip tile) and demands
+bit-identical images, live-ray counts and shadow-ray counts."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402
+from __graft_entry__ import load_package  # noqa: E402
+from test_gpu_parity import _random_scene  # noqa: E402
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    pkg = load_package()
+    from project3_pathtracer_amd import sharding
+    bad = 0
+    t0 = time.time()
+    for case in range(seed0, seed0 + cases):
+        rng = np.random.default_rng(90000 + case)
+        n_prims = int(rng.choice([2, 3, 5, 9, 14, 33, 60, 97, 130, 300]))
+        geoms, mats, eye, view, up, fovy = _random_scene(5000 + case, n_prims)
+        if rng.random() < 0.3:
+            mats[3].absorptionCoefficient = O.v3(*rng.uniform(0, 3, 3))
+        W, H = int(rng.integers(1, 90)), int(rng.integers(1, 60))
+        depth = int(rng.integers(1, 10))
+        iters = int(rng.integers(1, 5))
+        opts = dict(rr_start=int(rng.integers(-1, depth)), seed=int(rng.integers(0, 1000)))
+        gopts = dict(geom_path=int(rng.choice([0, 1, 2, 3, 4, 5, 6])), batch=int(rng.choice([0, 1, 2, 3, 7, 16])))
+        if rng.random() < 0.4:
+            opts["direct_light"] = 1
+        if rng.random() < 0.4:
+            opts["absorption"] = 1
+        if rng.random() < 0.3:
+            opts["lens_radius"] = float(np.float32(rng.uniform(0.05, 0.6)))
+            opts["focal_distance"] = float(np.float32(rng.uniform(2, 12)))
+        strip = None
+        if rng.random() < 0.3 and H >= 4:
+            world = int(rng.integers(2, 4))
+            srows = int(rng.integers(1, max(2, H // world)))
+            if srows * world <= H + srows - 1:
+                strip = (srows, world, int(rng.integers(0, world)))
+        ga = (O.StaticGeom * len(geoms))(*geoms)
+        ma = (O.Material * len(mats))(*mats)
+        cam = O.make_camera(W, H, eye, view, up, fovy)
+        sh = []
+        ref, live = O.render(ga, len(geoms), ma, len(mats), cam, depth, iters=iters, shadow_out=sh, **opts)
+        try:
+            with pkg.Renderer(0) as r:
+                so = dict(strip_rows=strip[0], strip_world=strip[1], strip_rank=strip[2]) if strip else {}
+                r.set_options(depth=depth, **opts, **gopts, **so)
+                r.set_scene(C.cast(ga, C.POINTER(pkg.StaticGeom)), len(geoms), C.cast(ma, C.POINTER(pkg.Material)), len(mats))
+                r.set_camera(pkg.CameraData.from_buffer_copy(cam))
+                r.clear_image()
+                r.render(1, iters)
+                img = r.download_image()
+                st = r.stats()
+        except pkg.PtError as e:
+            if "LDS" in str(e) and gopts["geom_path"] in (2, 3, 5):      # explicit LDS-resident path, scene too large for it
+                continue
+            raise
+        if strip:
+            want = ref[sharding.strip_global_rows(H, strip[1], strip[2], strip[0])]
+            ok = np.array_equal(img.view(np.uint32), want.view(np.uint32))
+        else:
+            ok = (np.array_equal(img.view(np.uint32), ref.view(np.uint32)) and
+                  [int(x) for x in st.live_in[:depth]] == [int(x) for x in live] and int(st.shadow_rays) == sh[0])
+        if not ok:
+            bad += 1
+            print(f"MISMATCH case {case}: prims={n_prims} {W}x{H} depth={depth} iters={iters} {opts} {gopts} strip={strip} "
+                  f"max|d|={np.abs(img - (want if strip else ref)).max():g}", flush=True)
+        if (case - seed0) % 25 == 24:
+            print(f"... {case - seed0 + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+    print(f"fuzz: {cases} cases, {bad} mismatches")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

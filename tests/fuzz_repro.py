@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Re-run single fuzz cases with option toggles: python tests/fuzz_repro.py <case> ..."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402
+from __graft_entry__ import load_package  # noqa: E402
+from test_gpu_parity import _random_scene  # noqa: E402
+
+pkg = load_package()
+
+
+def run(case, override):
+    rng = np.random.default_rng(90000 + case)
+    n_prims = int(rng.choice([2, 3, 5, 9, 14, 33, 60, 97, 130, 300]))
+    geoms, mats, eye, view, up, fovy = _random_scene(5000 + case, n_prims)
+    if rng.random() < 0.3:
+        mats[3].absorptionCoefficient = O.v3(*rng.uniform(0, 3, 3))
+    W, H = int(rng.integers(1, 90)), int(rng.integers(1, 60))
+    depth = int(rng.integers(1, 10))
+    iters = int(rng.integers(1, 5))
+    opts = dict(rr_start=int(rng.integers(-1, depth)), seed=int(rng.integers(0, 1000)))
+    gopts = dict(geom_path=int(rng.choice([0, 1, 2, 3, 4, 5, 6])), batch=int(rng.choice([0, 1, 2, 3, 7, 16])))
+    if rng.random() < 0.4:
+        opts["direct_light"] = 1
+    if rng.random() < 0.4:
+        opts["absorption"] = 1
+    if rng.random() < 0.3:
+        opts["lens_radius"] = float(np.float32(rng.uniform(0.05, 0.6)))
+        opts["focal_distance"] = float(np.float32(rng.uniform(2, 12)))
+    for k, v in override.items():
+        if k in ("geom_path", "batch"):
+            gopts[k] = v
+        elif k == "iters":
+            iters = v
+        elif k == "depth":
+            depth = v
+        elif v is None:
+            opts.pop(k, None)
+        else:
+            opts[k] = v
+    ga = (O.StaticGeom * len(geoms))(*geoms)
+    ma = (O.Material * len(mats))(*mats)
+    cam = O.make_camera(W, H, eye, view, up, fovy)
+    sh = []
+    ref, live = O.render(ga, len(geoms), ma, len(mats), cam, depth, iters=iters, shadow_out=sh, **opts)
+    with pkg.Renderer(0) as r:
+        r.set_options(depth=depth, **opts, **gopts)
+        r.set_scene(C.cast(ga, C.POINTER(pkg.StaticGeom)), len(geoms), C.cast(ma, C.POINTER(pkg.Material)), len(mats))
+        r.set_camera(pkg.CameraData.from_buffer_copy(cam))
+        r.clear_image()
+        r.render(1, iters)
+        img = r.download_image()
+        st = r.stats()
+    d = np.abs(img - ref)
+    print(f"case {case} {override}: {W}x{H} depth={depth} iters={iters} {opts} {gopts}: max|d|={d.max():g} "
+          f"live gpu={[int(x) for x in st.live_in[:depth]]} cpu={[int(x) for x in live]} shadows {int(st.shadow_rays)}/{sh[0]}")
+    if d.max() > 0:
+        ys, xs = np.nonzero(d.max(axis=2))
+        for y, x in list(zip(ys, xs))[:4]:
+            print("   px", x, y, "gpu", img[y, x], "cpu", ref[y, x])
+
+
+if __name__ == "__main__":
+    for c in sys.argv[1:]:
+        c = int(c)
+        run(c, {})
+        for ov in ({"iters": 1}, {"batch": 1}, {"geom_path": 1}, {"geom_path": 3}, {"geom_path": 5}, {"absorption": None},
+                   {"direct_light": None}, {"lens_radius": None}, {"rr_start": -1}, {"depth": 2}):
+            run(c, ov)

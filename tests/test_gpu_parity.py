@@ -693,3 +693,14 @@ def test_lens_options_are_validated(pkg):
             with pytest.raises(pkg.PtError):
                 r.set_options(**bad)
             r.set_options(lens_radius=0.0, focal_distance=1.0)
+
+
+@pytest.mark.parametrize("w,h,iters,batch", [(1, 8, 3, 0), (18, 1, 4, 3), (5, 5, 16, 16), (63, 1, 7, 16), (65, 1, 5, 4)])
+def test_tiny_tiles_with_several_iterations_in_flight(pkg, w, h, iters, batch):
+    """Fewer than 64 pixels per iteration slot: one 64-ray chunk of the camera kernel spans several slots (found by
+    tests/fuzz_gpu.py: the one-boundary shortcut of the slot computation does not apply there)."""
+    g, lg, _ = gpu_render(pkg, "sampleScene_spec.txt", w, h, 3, iters=iters, batch=batch, direct_light=1)
+    sc = O.LoadedScene(os.path.join(SCENES, "sampleScene_spec.txt"))
+    sc.set_resolution(w, h)
+    c, lc = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, 3, iters=iters, direct_light=1)
+    check(g, c, lg, [int(x) for x in lc], f"{w}x{h} x{iters} batch {batch}")
