@@ -7,6 +7,7 @@ work) must be equal.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -704,3 +705,15 @@ def test_tiny_tiles_with_several_iterations_in_flight(pkg, w, h, iters, batch):
     sc.set_resolution(w, h)
     c, lc = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, 3, iters=iters, direct_light=1)
     check(g, c, lg, [int(x) for x in lc], f"{w}x{h} x{iters} batch {batch}")
+
+
+def test_fuzz_sample(pkg):
+    """A slice of tests/fuzz_gpu.py (random scenes x random option mixes, bit-exact vs the oracle) on every run; the full
+    run (`python tests/fuzz_gpu.py 8000`) takes about half a minute on the GPU box."""
+    import fuzz_gpu
+    old = sys.argv
+    try:
+        sys.argv = ["fuzz_gpu.py", "120", "777000"]
+        assert fuzz_gpu.main() == 0
+    finally:
+        sys.argv = old
