@@ -57,6 +57,42 @@ def main():
         cam = O.make_camera(W, H, eye, view, up, fovy)
         sh = []
         ref, live = O.render(ga, len(geoms), ma, len(mats), cam, depth, iters=iters, shadow_out=sh, **opts)
+        if strip is None and rng.random() < 0.25 and H >= 4:
+            # the single-process multi-device handle (several contexts on device 0): bands or strips, host gather
+            ndev = int(rng.integers(1, 5))
+            srows = int(rng.choice([0, 1, 2, 8]))
+            if ndev <= H and (srows == 0 or srows * ndev <= H + srows - 1):
+                L = pkg.lib()
+                devs = (C.c_int * ndev)(*([0] * ndev))
+                m = C.c_void_p()
+                assert L.pt_multi_create(devs, ndev, C.byref(m)) == 0
+                try:
+                    o = pkg.Options()
+                    L.pt_default_options(C.byref(o))
+                    o.depth = depth
+                    for k, v in dict(opts, **gopts).items():
+                        setattr(o, k, v)
+                    if gopts["geom_path"] in (2, 3, 5) and n_prims > 200:
+                        o.geom_path = 0
+                    assert L.pt_multi_set_options(m, C.byref(o)) == 0, L.pt_last_error()
+                    assert L.pt_multi_set_strips(m, srows) == 0
+                    assert L.pt_multi_set_scene(m, C.cast(ga, C.POINTER(pkg.StaticGeom)), len(geoms), C.cast(ma, C.POINTER(pkg.Material)), len(mats)) == 0
+                    assert L.pt_multi_set_camera(m, C.cast(C.byref(cam), C.POINTER(pkg.CameraData))) == 0
+                    assert L.pt_multi_clear_image(m) == 0
+                    assert L.pt_multi_render(m, 1, iters) == 0, L.pt_last_error()
+                    host = np.zeros((H, W, 3), dtype=np.float32)
+                    assert L.pt_multi_download_image(m, host.ctypes.data) == 0
+                    st = pkg.Stats()
+                    assert L.pt_multi_get_stats(m, C.byref(st)) == 0
+                finally:
+                    L.pt_multi_destroy(m)
+                ok = (np.array_equal(host.view(np.uint32), ref.view(np.uint32)) and
+                      [int(x) for x in st.live_in[:depth]] == [int(x) for x in live] and int(st.shadow_rays) == sh[0])
+                if not ok:
+                    bad += 1
+                    print(f"MISMATCH (multi) case {case}: ndev={ndev} strips={srows} prims={n_prims} {W}x{H} depth={depth} iters={iters} "
+                          f"{opts} {gopts} max|d|={np.abs(host - ref).max():g}", flush=True)
+                continue
         try:
             with pkg.Renderer(0) as r:
                 so = dict(strip_rows=strip[0], strip_world=strip[1], strip_rank=strip[2]) if strip else {}
