@@ -83,6 +83,29 @@ __device__ __forceinline__ float rsqrt_rn(float s)                     // == 1.0
     return 1.0f / sqrtf(s);
 }
 
+// 1.0f / sqrtf(s) for call sites whose argument is the squared length of an (almost) unit vector: getPointOnRay
+// re-normalises a direction that is already normalised, and the second tangent of the hemisphere frame is the cross
+// product of two orthogonal unit vectors.  Within 1024 ulp of 1.0 the doubly rounded result follows from the bit
+// pattern alone (k = distance from 1.0 in ulps; sqrt halves it rounding towards 1 -- the series' second-order term
+// breaks the ties --, the reciprocal mirrors it across 1.0 where the spacing changes by 2); checked for every input
+// by pt_selftest_math.  No v_sqrt / v_rcp: 8 integer operations instead of ~22 with two quarter-rate ones.
+__device__ __forceinline__ float rsqrt_near_one(float s)
+{
+    const uint32_t b = __float_as_uint(s);
+    if (__builtin_amdgcn_uicmp(b - (0x3F800000u - 1024u), 2048u, 34 /* ICMP_UGT */) == 0ull) {
+        const int k = (int)(b - 0x3F800000u);
+        const uint32_t above = 0x3F800000u - ((uint32_t)k & ~1u);                                 // s >= 1
+        const uint32_t below = 0x3F800000u + (((((uint32_t)(-k) + 1u) >> 1) + 1u) >> 1);          // s < 1
+        return __uint_as_float(k >= 0 ? above : below);
+    }
+    return rsqrt_rn(s);
+}
+__device__ __forceinline__ f3 normalize_unit(f3 v)          // normalize() of a vector that is (almost) unit length already
+{
+    float inv = rsqrt_near_one(v.x * v.x + v.y * v.y + v.z * v.z);
+    return mk(v.x * inv, v.y * inv, v.z * inv);
+}
+
 __device__ __forceinline__ float length(f3 v) { return sqrt_rn(v.x * v.x + v.y * v.y + v.z * v.z); }
 __device__ __forceinline__ f3 normalize(f3 v)
 {
@@ -184,7 +207,7 @@ __device__ __forceinline__ f3 mulMV(const float *m, f3 v, float w)
 }
 
 // getPointOnRay (ref: src/intersections.h:46-48)
-__device__ __forceinline__ f3 pointOnRay(f3 o, f3 d, float t) { return o + (t - .0001f) * normalize(d); }
+__device__ __forceinline__ f3 pointOnRay(f3 o, f3 d, float t) { return o + (t - .0001f) * normalize_unit(d); }
 
 // ---------------------------------------------------------------------------------------------
 // One primitive against one ray, split into the three stages the kernels schedule separately:
@@ -316,7 +339,7 @@ __device__ __forceinline__ f3 randomDirectionInHemisphere(f3 normal, float xi1, 
     else if (fabsf(normal.y) < 0.5773503184318542f) notNormal = mk(0, 1, 0);
     else notNormal = mk(0, 0, 1);
     f3 p1 = normalize(cross(normal, notNormal));
-    f3 p2 = normalize(cross(normal, p1));
+    f3 p2 = normalize_unit(cross(normal, p1));
     float sn, cs;
     sincos_poly(around, sn, cs);
     return ((up * normal) + ((cs * over) * p1)) + ((sn * over) * p2);

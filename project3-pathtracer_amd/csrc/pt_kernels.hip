@@ -1257,8 +1257,9 @@ __global__ __launch_bounds__(256) void k_selftest_math(unsigned long long *out)
         if (__float_as_uint(a) != __float_as_uint(b) && !(a != a && b != b)) bad0++;
         const float c = 1.0f / x, d = rcp_rn(x);
         if (__float_as_uint(c) != __float_as_uint(d) && !(c != c && d != d)) bad1++;
-        const float e = 1.0f / sqrtf(x), f = rsqrt_rn(x);
+        const float e = 1.0f / sqrtf(x), f = rsqrt_rn(x), g = rsqrt_near_one(x);
         if (__float_as_uint(e) != __float_as_uint(f) && !(e != e && f != f)) bad2++;
+        if (__float_as_uint(e) != __float_as_uint(g) && !(e != e && g != g)) bad2++;
     }
     if (bad0) atomicAdd(&out[0], bad0);
     if (bad1) atomicAdd(&out[1], bad1);
