@@ -68,6 +68,7 @@ struct pt_ctx {
     ptd::Prim *d_prims = nullptr;
     float *d_mats = nullptr;
     float *d_ro_eye = nullptr;
+    float *d_face_n = nullptr;
     float *d_box_eye = nullptr;
     float *d_box_world = nullptr;
     int *d_lights = nullptr;    // direct lighting: indices of the emissive primitives
@@ -374,6 +375,27 @@ int configure(pt_ctx *c)
         HIP_TRY(hipMalloc((void **)&c->d_ro_eye, ro.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(c->d_ro_eye, ro.data(), ro.size() * sizeof(float), hipMemcpyHostToDevice));
 
+        // The world normal of a box face depends on (primitive, face) only: normalize(multiplyMV(transform, (+-axis, 0)))
+        // evaluated here once with the kernels' operation order (boxNormal in pt_device.h), looked up per hit.
+        std::vector<float> fnorm(prims.size() * 32, 0.0f);
+        for (size_t i = 0; i < c->geoms.size(); ++i) {
+            const pt_mat4 &m = c->geoms[i].transform;
+            for (int face = 0; face < 8; ++face) {
+                const int axis = face & 3;
+                if (axis == 3) continue;
+                const float sgn = (face & 4) ? -1.0f : 1.0f;
+                const float nx = axis == 0 ? sgn : 0.0f, ny = axis == 1 ? sgn : 0.0f, nz = axis == 2 ? sgn : 0.0f;
+                const v3 w = {(m.x.x * nx) + (m.x.y * ny) + (m.x.z * nz) + (m.x.w * 0.0f),
+                              (m.y.x * nx) + (m.y.y * ny) + (m.y.z * nz) + (m.y.w * 0.0f),
+                              (m.z.x * nx) + (m.z.y * ny) + (m.z.z * nz) + (m.z.w * 0.0f)};
+                const v3 n = normalize3(w);
+                fnorm[i * 32 + (size_t)face * 4 + 0] = n.x; fnorm[i * 32 + (size_t)face * 4 + 1] = n.y; fnorm[i * 32 + (size_t)face * 4 + 2] = n.z;
+            }
+        }
+        if (c->d_face_n) { (void)hipFree(c->d_face_n); c->d_face_n = nullptr; }
+        HIP_TRY(hipMalloc((void **)&c->d_face_n, fnorm.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(c->d_face_n, fnorm.data(), fnorm.size() * sizeof(float), hipMemcpyHostToDevice));
+
         // ... and a wave of camera rays covers a small solid angle: the padded world box of every primitive,
         // relative to the eye, lets a wave skip the primitives none of its rays can reach (culling only)
         std::vector<float> be(prims.size() * 8, 0.0f), bw(prims.size() * 8, 0.0f);
@@ -415,6 +437,8 @@ int configure(pt_ctx *c)
     }
     k.prims = c->d_prims;
     k.ro_eye = c->d_ro_eye;
+    k.face_n = c->d_face_n;
+
     k.box_eye = c->d_box_eye;
     k.eye_cull = getenv("PT_NO_EYE_CULL") ? 0 : 1;
     k.box_world = c->d_box_world;
@@ -484,6 +508,11 @@ int configure(pt_ctx *c)
     cfg.nee = k.nlights > 0 ? 1 : 0;             // no lights: nothing to sample, the plain kernels are exact
     k.cull = (k.nG > 32 && !getenv("PT_NO_CULL")) ? 1 : 0;
     k.nshard = (cfg.compact == 1) ? pt::NSHARD : 1;
+    // Ray prefetch costs 2.5 KiB of LDS per wave and gains a few per cent; one workgroup per CU less costs 7 % (measured:
+    // 5 workgroups of 256 threads stay resident up to about 31 KiB each -- the occupancy query keeps saying 5 beyond
+    // that, the throughput does not).  So it is on only while the total stays below that mark.
+    k.prefetch = 1;
+    if (pt::bounce_lds_bytes(k, cfg) > 31 * 1024) k.prefetch = 0;
     size_t lds = pt::bounce_lds_bytes(k, cfg);
     if (lds > 160 * 1024 && o.geom_path == 0) {
         // the hierarchy (32 B per node, 2 nodes per primitive) no longer fits the CU's LDS: fall back to the scalar
@@ -508,6 +537,9 @@ int configure(pt_ctx *c)
     if (grid > want) grid = want;
     if (grid < 1) grid = 1;
     cfg.grid = (int)grid;
+    if (getenv("PT_DEBUG_CLOCK"))
+        fprintf(stderr, "[ptamd] launch: geom %d, workgroup %d, %zu B LDS, %d workgroups/CU, grid %d, batch %d\n", cfg.geom, cfg.workgroup,
+                lds, per_cu, cfg.grid, batch);
 
     // per-iteration radiance planes (one write per path, folded into the image by k_accumulate)
     const size_t lbuf_bytes = (size_t)nrays * 3 * sizeof(float);
@@ -660,6 +692,7 @@ void pt_destroy(pt_ctx *c)
     if (c->d_prims) (void)hipFree(c->d_prims);
     if (c->d_mats) (void)hipFree(c->d_mats);
     if (c->d_ro_eye) (void)hipFree(c->d_ro_eye);
+    if (c->d_face_n) (void)hipFree(c->d_face_n);
     if (c->d_box_eye) (void)hipFree(c->d_box_eye);
     if (c->d_box_world) (void)hipFree(c->d_box_world);
     if (c->d_lights) (void)hipFree(c->d_lights);

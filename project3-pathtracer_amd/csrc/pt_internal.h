@@ -59,6 +59,8 @@ struct KParams {
     int nnodes;
     int nbig;              // primitives too large to cull (walls...): tested by every ray before the walk
     int big[16];           // their indices
+    int prefetch;          // 1 = later bounces of the pair-queue path prefetch their rays into LDS (decided by the host)
+    const float *face_n;   // per primitive: 8 float4, entry `face code` = world normal of that box face (boxNormal's result)
     const float *ro_eye;   // per primitive: inverseTransform*(eye,1) as float4 (camera rays share their origin)
     int eye_cull;          // 1 = camera-ray waves skip primitives outside their boxes (box_eye), ablation switch
     const float *box_world; // per primitive: padded world box (lo.xyz,0)(hi.xyz,0): per-lane pre-test of the pair queue

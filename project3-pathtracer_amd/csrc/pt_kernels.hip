@@ -255,7 +255,10 @@ __device__ __forceinline__ Hit nearestHitBvh(const KParams &p, const Prim *s_pri
         const Prim &P = s_prims[best_g];
         h.material = P.material;
         if (P.type == 0u) h.n = sphereNormal(h.p, mk(P.cx, P.cy, P.cz));
-        else h.n = boxNormal(P.fwd, best_face);
+        else {
+            const float4 fn = reinterpret_cast<const float4 *>(p.face_n)[best_g * 8u + best_face];
+            h.n = mk(fn.x, fn.y, fn.z);
+        }
     }
     if (DEBUG_BVH) {
         // per ray: nodes, leaves; per wave: the longest lane (what the wave pays)
@@ -386,10 +389,8 @@ __device__ __forceinline__ Hit nearestHitQueued(const KParams &p, const Prim *s_
             const float4 c = *reinterpret_cast<const float4 *>(&P.cx);
             h.n = sphereNormal(h.p, mk(c.x, c.y, c.z));
         } else {
-            const float4 *fw = reinterpret_cast<const float4 *>(P.fwd);
-            const float4 f0 = fw[0], f1 = fw[1], f2 = fw[2];
-            const float fwd[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
-            h.n = boxNormal(fwd, face);
+            const float4 fn = reinterpret_cast<const float4 *>(s_prims + p.nG)[prim * 8u + face];   // face-normal table behind the records
+            h.n = mk(fn.x, fn.y, fn.z);
         }
     }
     return h;
@@ -402,10 +403,11 @@ struct PairQueue {
     uint32_t *q[2];               // [QCAP] pending pairs, lane | prim << 8: [0] spheres, [1] boxes
     unsigned long long *key;      // [64] per owner lane: min over hits of (distance bits << 32 | prim << 8)
     float4 *best;                 // [64] per owner lane: (hit point xyz, meta) of the current minimum
-    float4 *org, *dir;            // [64] per owner lane: the ray
+    float4 *org;                  // [64] per owner lane: the ray, (origin.xyz, direction.x) ...
+    float2 *dir;                  // [64] ... (direction.y, direction.z)
     unsigned long long *dbg;
 };
-static constexpr uint32_t PAIR_QUEUE_BYTES = 2 * QCAP * 4 + 64 * 8 + 3 * 64 * 16;
+static constexpr uint32_t PAIR_QUEUE_BYTES = 2 * QCAP * 4 + 64 * 8 + 2 * 64 * 16 + 64 * 8;
 static_assert(PAIR_QUEUE_BYTES <= WAVE_QUEUE_BYTES, "the pair queue lives in the hit queue's LDS region");
 
 // one batch: lane l takes pair head + l of queue TYPE (0 sphere, 1 box), whoever owns it.  TYPE 2 = the last, mixed
@@ -424,8 +426,9 @@ __device__ __forceinline__ void pairBatch(const KParams &p, const Prim *s_prims,
                                                       : q.q[TYPE == 2u ? 0u : TYPE][(head + lane) & (QCAP - 1u)];
         owner = e & 63u;
         const uint32_t prim = e >> 8;
-        const float4 oo = q.org[owner], dd = q.dir[owner];
-        const f3 o = mk(oo.x, oo.y, oo.z), d = mk(dd.x, dd.y, dd.z);
+        const float4 oo = q.org[owner];
+        const float2 dd = q.dir[owner];
+        const f3 o = mk(oo.x, oo.y, oo.z), d = mk(oo.w, dd.x, dd.y);
         const float4 *iv = reinterpret_cast<const float4 *>(s_prims[prim].inv);
         const float4 i0 = iv[0], i1 = iv[1], i2 = iv[2];
         const float inv[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
@@ -461,8 +464,8 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const Prim *s_p
                                                f3 o, f3 d, bool valid, uint32_t lane)
 {
     q.key[lane] = KEY_NONE;
-    q.org[lane] = make_float4(o.x, o.y, o.z, 0.0f);
-    q.dir[lane] = make_float4(d.x, d.y, d.z, 0.0f);
+    q.org[lane] = make_float4(o.x, o.y, o.z, d.x);
+    q.dir[lane] = make_float2(d.y, d.z);
     uint32_t head[2] = {0u, 0u}, tail[2] = {0u, 0u};        // wave-uniform
     const uint64_t vmask = __ballot(valid);
     const f3 dinv = approxInverse(d);
@@ -536,10 +539,8 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const Prim *s_p
             const float4 c = *reinterpret_cast<const float4 *>(&P.cx);
             h.n = sphereNormal(h.p, mk(c.x, c.y, c.z));
         } else {
-            const float4 *fw = reinterpret_cast<const float4 *>(P.fwd);
-            const float4 f0 = fw[0], f1 = fw[1], f2 = fw[2];
-            const float fwd[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
-            h.n = boxNormal(fwd, face);
+            const float4 fn = reinterpret_cast<const float4 *>(s_prims + p.nG)[prim * 8u + face];   // face-normal table behind the records
+            h.n = mk(fn.x, fn.y, fn.z);
         }
     }
     return h;
@@ -589,8 +590,8 @@ __device__ __forceinline__ Hit nearestHitWalkPairs(const KParams &p, const Prim 
                                                    f3 o, f3 d, bool valid, uint32_t lane)
 {
     q.key[lane] = KEY_NONE;
-    q.org[lane] = make_float4(o.x, o.y, o.z, 0.0f);
-    q.dir[lane] = make_float4(d.x, d.y, d.z, 0.0f);
+    q.org[lane] = make_float4(o.x, o.y, o.z, d.x);
+    q.dir[lane] = make_float2(d.y, d.z);
     uint32_t head[2] = {0u, 0u}, tail[2] = {0u, 0u};        // wave-uniform
     const f3 dinv = approxInverse(d);
     const f3 oinv = mk(-(o.x * dinv.x), -(o.y * dinv.y), -(o.z * dinv.z));
@@ -715,7 +716,10 @@ __device__ __forceinline__ Hit nearestHitWalkPairs(const KParams &p, const Prim 
         h.p = mk(b.x, b.y, b.z);
         h.material = P.material;
         if (P.type == 0u) h.n = sphereNormal(h.p, mk(P.cx, P.cy, P.cz));
-        else h.n = boxNormal(P.fwd, face);
+        else {
+            const float4 fn = reinterpret_cast<const float4 *>(p.face_n)[prim * 8u + face];
+            h.n = mk(fn.x, fn.y, fn.z);
+        }
     }
     return h;
 }
@@ -735,7 +739,7 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const Prim *s_prims,
         pq.key = reinterpret_cast<unsigned long long *>(b + 2 * QCAP * 4);
         pq.best = reinterpret_cast<float4 *>(b + 2 * QCAP * 4 + 64 * 8);
         pq.org = reinterpret_cast<float4 *>(b + 2 * QCAP * 4 + 64 * 8 + 64 * 16);
-        pq.dir = reinterpret_cast<float4 *>(b + 2 * QCAP * 4 + 64 * 8 + 2 * 64 * 16);
+        pq.dir = reinterpret_cast<float2 *>(b + 2 * QCAP * 4 + 64 * 8 + 2 * 64 * 16);
         pq.dbg = p.st->dbg;
         if (GEOM == GEOM_WALK_PAIR) return nearestHitWalkPairs<FIRST>(p, p.prims, s_nodes, pq, o, d, want, lane);
         return nearestHitPairs<FIRST>(p, s_prims, s_nodes, pq, o, d, want, lane);
@@ -779,7 +783,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     // LDS carve: [prims nG*128 B (GEOM 1,2)] [per-wave hit queues (GEOM 2)] [material planes] [scan scratch]
     Prim *s_prims = reinterpret_cast<Prim *>(smem);
-    const int prim_bytes = PRIMS_IN_LDS ? p.nG * (int)sizeof(Prim) : 0;
+    const int prim_bytes = PRIMS_IN_LDS ? p.nG * (int)(sizeof(Prim) + 128) : 0;      // records, then 8 face normals each
     const float4 *s_nodes = reinterpret_cast<const float4 *>(smem + prim_bytes);
     // pair queue: the same region holds the primitives' padded boxes (2 float4 each; relative to the eye for camera rays)
     const int node_bytes = (GEOM == GEOM_BVH || GEOM == GEOM_WALK_PAIR) ? p.nnodes * (int)sizeof(BvhNode)
@@ -791,7 +795,8 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
     float *s_mats = reinterpret_cast<float *>(s_queue + queue_bytes);
     const int mat_words = (p.nM * M_PLANES + 3) & ~3;
     uint32_t *s_scan = reinterpret_cast<uint32_t *>(s_mats + mat_words);   // [2][NW] wave totals, [2] bases
-    constexpr bool PREFETCH = PT_RAY_PREFETCH && GEOM == GEOM_PAIR && !FIRST && COMPACT != 0;
+    constexpr bool PREFETCH_BUILT = PT_RAY_PREFETCH && GEOM == GEOM_PAIR && !FIRST && COMPACT != 0;
+    const bool PREFETCH = PREFETCH_BUILT && p.prefetch != 0;      // the host turns it off when its LDS would cost a workgroup per CU
     constexpr int SCAN_WORDS = (2 * NW + 2 + 3) & ~3;
     unsigned char *const s_ray = reinterpret_cast<unsigned char *>(s_scan + SCAN_WORDS) + (threadIdx.x >> 6) * RAY_LDS_BYTES;   // [a 1024][b 1024][c.x 256][c.y 256]
     typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
@@ -816,6 +821,8 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
         const uint4 *src = reinterpret_cast<const uint4 *>(p.prims);
         uint4 *dst = reinterpret_cast<uint4 *>(s_prims);
         for (int k = tid; k < p.nG * 8; k += WG) dst[k] = src[k];
+        const uint4 *fsrc = reinterpret_cast<const uint4 *>(p.face_n);
+        for (int k = tid; k < p.nG * 8; k += WG) dst[p.nG * 8 + k] = fsrc[k];
     }
     if (GEOM == GEOM_PAIR) {
         const uint4 *src = reinterpret_cast<const uint4 *>((FIRST && !(p.lens_radius > 0.0f)) ? p.box_eye : p.box_world);
@@ -1417,14 +1424,14 @@ __global__ __launch_bounds__(256) void k_send_image_to_pbo(pt_uchar4 *pbo, const
 // ---------------------------------------------------------------------------------------------
 size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg)
 {
-    size_t prim = (cfg.geom == GEOM_LDS || cfg.geom == GEOM_QUEUE || cfg.geom == GEOM_PAIR) ? (size_t)p.nG * sizeof(Prim) : 0;
+    size_t prim = (cfg.geom == GEOM_LDS || cfg.geom == GEOM_QUEUE || cfg.geom == GEOM_PAIR) ? (size_t)p.nG * (sizeof(Prim) + 128) : 0;
     size_t queue = (size_t)(cfg.workgroup / 64) * (cfg.geom == GEOM_QUEUE ? WAVE_QUEUE_BYTES
                                                    : ((cfg.geom == GEOM_PAIR || cfg.geom == GEOM_WALK_PAIR) ? PAIR_QUEUE_BYTES : 0));
     if (cfg.geom == GEOM_BVH || cfg.geom == GEOM_WALK_PAIR) prim += (size_t)p.nnodes * sizeof(BvhNode);
     if (cfg.geom == GEOM_PAIR) prim += (size_t)p.nG * 32 * (cfg.nee ? 2 : 1);
     size_t mats = (size_t)((p.nM * M_PLANES + 3) & ~3) * sizeof(float);
     size_t scan = (size_t)((2 * (cfg.workgroup / 64) + 2 + 3) & ~3) * sizeof(uint32_t);
-    if (PT_RAY_PREFETCH && cfg.geom == GEOM_PAIR && cfg.compact != 0) scan += (size_t)(cfg.workgroup / 64) * RAY_LDS_BYTES;   // ray prefetch slots
+    if (PT_RAY_PREFETCH && cfg.geom == GEOM_PAIR && cfg.compact != 0 && p.prefetch) scan += (size_t)(cfg.workgroup / 64) * RAY_LDS_BYTES;   // ray prefetch slots
     static const size_t extra = getenv("PT_EXTRA_LDS") ? (size_t)atol(getenv("PT_EXTRA_LDS")) : 0;   // occupancy experiments
     return prim + queue + mats + scan + extra;
 }
