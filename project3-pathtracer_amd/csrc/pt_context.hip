@@ -508,11 +508,12 @@ int configure(pt_ctx *c)
     cfg.nee = k.nlights > 0 ? 1 : 0;             // no lights: nothing to sample, the plain kernels are exact
     k.cull = (k.nG > 32 && !getenv("PT_NO_CULL")) ? 1 : 0;
     k.nshard = (cfg.compact == 1) ? pt::NSHARD : 1;
-    // Ray prefetch costs 2.5 KiB of LDS per wave and gains a few per cent; one workgroup per CU less costs 7 % (measured:
-    // 5 workgroups of 256 threads stay resident up to about 31 KiB each -- the occupancy query keeps saying 5 beyond
-    // that, the throughput does not).  So it is on only while the total stays below that mark.
-    k.prefetch = 1;
-    if (pt::bounce_lds_bytes(k, cfg) > 31 * 1024) k.prefetch = 0;
+    // Ray prefetch (LDS-DMA, 2.5 KiB of LDS per wave) is built but off: with the scalar chunk bookkeeping in place it
+    // is neutral at equal occupancy (33.3 vs 34.0 G at 5 workgroups/CU) and its LDS keeps the kernel from the 6
+    // workgroups/CU where it runs best.  PT_PREFETCH=1 turns it on for experiments (never past the ~31 KiB mark where a
+    // fifth workgroup stops fitting although the occupancy query still counts it).
+    k.prefetch = getenv("PT_PREFETCH") ? atoi(getenv("PT_PREFETCH")) : 0;
+    if (k.prefetch && pt::bounce_lds_bytes(k, cfg) > 31 * 1024) k.prefetch = 0;
     size_t lds = pt::bounce_lds_bytes(k, cfg);
     if (lds > 160 * 1024 && o.geom_path == 0) {
         // the hierarchy (32 B per node, 2 nodes per primitive) no longer fits the CU's LDS: fall back to the scalar
@@ -524,6 +525,12 @@ int configure(pt_ctx *c)
     int per_cu = pt::bounce_max_blocks_per_cu(k, cfg);
     if (per_cu < 1) return fail(PT_ERR_HIP, "occupancy query failed for workgroup=%d (%s)", cfg.workgroup,
                                 hipGetErrorString(hipGetLastError()));
+    // Persistent grid: 6 workgroups of 256 threads per CU is the measured optimum (config 2: 4 -> 32.0, 5 -> 34.0,
+    // 6 -> 34.5, 7 -> 30.5 G ray-bounces/s; the same shape on the glass scene and at 4K): a seventh costs 11 %.
+    int cap = 6 * 256 / cfg.workgroup;
+    if (cap < 1) cap = 1;
+    if (getenv("PT_MAX_WG_PER_CU") && atoi(getenv("PT_MAX_WG_PER_CU")) > 0) cap = atoi(getenv("PT_MAX_WG_PER_CU"));
+    if (per_cu > cap) per_cu = cap;
     // iterations in flight per launch sequence: every bounce launch then carries batch x npix paths, which
     // amortises the per-launch fixed cost (launch, LDS staging, ramp, tail) over `batch` samples per pixel
     int batch = o.batch == 0 ? pt::PT_MAX_BATCH : o.batch;
