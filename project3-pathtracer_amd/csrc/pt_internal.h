@@ -24,7 +24,7 @@ struct RayPool {
 // Live-ray counters are sharded: survivors of a bounce are appended to one of NSHARD dense pool segments, each
 // with its own reservation counter on its own 128-byte line, so that per-wave reservations do not all queue on
 // one address (one global counter saturates near 88 M atomics/s on this chip).
-static constexpr int NSHARD = 8;
+static constexpr int NSHARD = 32;
 static constexpr int PT_MAX_BATCH = 16;         // iterations rendered concurrently by one launch sequence
 static constexpr int CNT_STRIDE = 32;            // uint32 per counter slot = 128 B
 __host__ __device__ constexpr int cnt_index(int bounce, int shard) { return (bounce * NSHARD + shard) * CNT_STRIDE; }
