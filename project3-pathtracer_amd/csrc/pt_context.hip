@@ -392,6 +392,31 @@ int configure(pt_ctx *c)
                 fnorm[i * 32 + (size_t)face * 4 + 0] = n.x; fnorm[i * 32 + (size_t)face * 4 + 1] = n.y; fnorm[i * 32 + (size_t)face * 4 + 2] = n.z;
             }
         }
+        // cube lights: the sampler's face-choice thresholds (ref: src/intersections.h:140-170, same fp32 operations),
+        // parked in the table's unused entries 3 (t1..t4) and 7 (t5)
+        for (size_t i = 0; i < c->geoms.size(); ++i) {
+            const pt_static_geom &g = c->geoms[i];
+            if (g.type != PT_CUBE) continue;
+            const pt_mat4 &m = g.transform;
+            auto mv = [&](float x, float y, float z, float out[3]) {
+                out[0] = (m.x.x * x) + (m.x.y * y) + (m.x.z * z) + (m.x.w * 1.0f);
+                out[1] = (m.y.x * x) + (m.y.y * y) + (m.y.z * z) + (m.y.w * 1.0f);
+                out[2] = (m.z.x * x) + (m.z.y * y) + (m.z.z * z) + (m.z.w * 1.0f);
+            };
+            float org[3], ax[3][3], r[3];
+            mv(0, 0, 0, org); mv(.5f, 0, 0, ax[0]); mv(0, .5f, 0, ax[1]); mv(0, 0, .5f, ax[2]);
+            for (int a2 = 0; a2 < 3; ++a2) {
+                const float dx = ax[a2][0] - org[0], dy = ax[a2][1] - org[1], dz = ax[a2][2] - org[2];
+                r[a2] = sqrtf(dx * dx + dy * dy + dz * dz);
+            }
+            const float side1 = r[0] * r[1] * 4.0f, side2 = r[2] * r[1] * 4.0f, side3 = r[0] * r[2] * 4.0f;
+            const float totalarea = 2.0f * (side1 + side2 + side3);
+            fnorm[i * 32 + 12 + 0] = side1 / totalarea;
+            fnorm[i * 32 + 12 + 1] = (side1 * 2) / totalarea;
+            fnorm[i * 32 + 12 + 2] = ((side1 * 2) + (side2)) / totalarea;
+            fnorm[i * 32 + 12 + 3] = ((side1 * 2) + (side2 * 2)) / totalarea;
+            fnorm[i * 32 + 28 + 0] = ((side1 * 2) + (side2 * 2) + (side3)) / totalarea;
+        }
         if (c->d_face_n) { (void)hipFree(c->d_face_n); c->d_face_n = nullptr; }
         HIP_TRY(hipMalloc((void **)&c->d_face_n, fnorm.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(c->d_face_n, fnorm.data(), fnorm.size() * sizeof(float), hipMemcpyHostToDevice));

@@ -475,6 +475,30 @@ __device__ __forceinline__ f3 calculateTransmission(f3 absorptionCoefficient, fl
               exp_poly(-absorptionCoefficient.z * distance));
 }
 
+// getRandomPointOnCube with the five face-choice thresholds (side areas over the total) and the face normals taken from
+// host-built tables: they depend on the light only (pt_context.hip evaluates them with this file's operation order).
+// tab = the primitive's 8-entry face table: entries 0-2 / 4-6 hold the +axis / -axis world normals, entry 3 holds the
+// thresholds t1..t4, entry 7.x holds t5.
+__device__ __forceinline__ void sampleCubeLightTab(const float *fwd, const float4 *tab, float randomSeed, f3 &point, f3 &normal)
+{
+    uint32_t rng = minstd_seed(wang_hash((uint32_t)randomSeed));
+    const float4 t = tab[3];
+    const float t5 = tab[7].x;
+    const float russianRoulette = uniform_real(rng, 0, 1);
+    const float a = uniform_real(rng, -0.5f, 0.5f), b = uniform_real(rng, -0.5f, 0.5f);
+    f3 pobj;
+    uint32_t face;
+    if (russianRoulette < t.x) { pobj = mk(a, b, .5f); face = 2u; }
+    else if (russianRoulette < t.y) { pobj = mk(a, b, -.5f); face = 6u; }
+    else if (russianRoulette < t.z) { pobj = mk(.5f, a, b); face = 0u; }
+    else if (russianRoulette < t.w) { pobj = mk(-.5f, a, b); face = 4u; }
+    else if (russianRoulette < t5) { pobj = mk(a, .5f, b); face = 1u; }
+    else { pobj = mk(a, -.5f, b); face = 5u; }
+    point = mulMV(fwd, pobj, 1.0f);
+    const float4 n = tab[face];
+    normal = mk(n.x, n.y, n.z);
+}
+
 // Direct lighting: a point on a light and the geometric normal there, from one float seed (the reference's sampler
 // interface).  Normals as the intersection tests define them (boxNormal / sphereNormal).
 __device__ __forceinline__ void sampleLight(uint32_t type, const float *fwd, f3 center, float randomSeed, f3 &point, f3 &normal)

@@ -1075,7 +1075,13 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
                         const float4 f0 = fw[0], f1 = fw[1], f2 = fw[2], cc = fw[3];   // fwd rows, (cx, cy, cz, bound)
                         const float fwd[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
                         f3 yl, nl;
-                        sampleLight(hd.x, fwd, mk(cc.x, cc.y, cc.z), u_seed * 16777216.0f, yl, nl);
+                        if (hd.x == 1u) {                            // cube light: thresholds and face normals from the table
+                            const float4 *tab = (PRIMS_IN_LDS ? reinterpret_cast<const float4 *>(s_prims + p.nG)
+                                                              : reinterpret_cast<const float4 *>(p.face_n)) + lprim * 8u;
+                            sampleCubeLightTab(fwd, tab, u_seed * 16777216.0f, yl, nl);
+                        } else {
+                            sampleLight(hd.x, fwd, mk(cc.x, cc.y, cc.z), u_seed * 16777216.0f, yl, nl);
+                        }
                         so = h.p + 0.0002f * nf;
                         const f3 wi = yl - so;
                         const float d2 = dot(wi, wi);
