@@ -550,6 +550,13 @@ int configure(pt_ctx *c)
     int per_cu = pt::bounce_max_blocks_per_cu(k, cfg);
     if (per_cu < 1) return fail(PT_ERR_HIP, "occupancy query failed for workgroup=%d (%s)", cfg.workgroup,
                                 hipGetErrorString(hipGetLastError()));
+    // The occupancy query over-counts near the LDS limit: 5 workgroups of 31.2 KB are resident together, 5 of 31.8 KB are
+    // not (measured), i.e. about 1.3 KB per workgroup is spoken for.  A persistent grid sized for workgroups that are not
+    // resident runs them as a second round (-7...-23 %), so the count is corrected here.
+    {
+        const long long fit = (160LL * 1024) / ((long long)lds + 1300);
+        if (fit >= 1 && per_cu > (int)fit) per_cu = (int)fit;
+    }
     // Persistent grid: 6 workgroups of 256 threads per CU is the measured optimum (config 2: 4 -> 32.0, 5 -> 34.0,
     // 6 -> 34.5, 7 -> 30.5 G ray-bounces/s; the same shape on the glass scene and at 4K): a seventh costs 11 %.
     int cap = 6 * 256 / cfg.workgroup;
