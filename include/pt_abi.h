@@ -84,7 +84,7 @@ typedef struct pt_options {
     int compaction;       /* live-ray compaction after every bounce: 1 = per-wave reservation in 8 pool segments, no
                              barrier (default); 2 = workgroup LDS scan + one counter; 0 = off, rays keep their slot */
     int workgroup;        /* threads per workgroup: 64, 128, 256, 512 or 1024 (default 0 = library choice) */
-    int geom_path;        /* how primitives reach the lanes: 0 = library choice (default: 5 up to 96 primitives, else 6),
+    int geom_path;        /* how primitives reach the lanes: 0 = library choice (default: 5 up to 40 primitives, else 6),
                              1 = scalar (SGPR) loads, 2 = staged in LDS, 3 = scalar candidate test + wave-private LDS hit
                              queue, 4 = per-lane walk of an LDS-resident bounding-box hierarchy (large scenes), 5 = per-lane
                              box pre-test + wave-private queue of (ray, primitive) pairs, exact test on full batches,

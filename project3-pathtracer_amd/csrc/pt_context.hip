@@ -527,8 +527,8 @@ int configure(pt_ctx *c)
     pt::LaunchCfg &cfg = c->cfg;
     cfg.workgroup = o.workgroup ? o.workgroup : 256;
     // library choice: the pair queue's pre-test is linear in the primitive count, the hierarchy walk logarithmic but
-    // divergent: measured crossover near 100 primitives (profiles/r01/crossover_pair_vs_walk.txt)
-    cfg.geom = o.geom_path == 0 ? (k.nG <= 96 ? 4 : 5) : o.geom_path - 1;
+    // divergent: measured crossover near 40 primitives (profiles/r01/crossover_pair_vs_walk.txt)
+    cfg.geom = o.geom_path == 0 ? (k.nG <= 40 ? 4 : 5) : o.geom_path - 1;
     cfg.compact = o.compaction;
     cfg.nee = k.nlights > 0 ? 1 : 0;             // no lights: nothing to sample, the plain kernels are exact
     k.cull = (k.nG > 32 && !getenv("PT_NO_CULL")) ? 1 : 0;
