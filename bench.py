@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- ray-bounces/s of the path-tracing hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 1..5] [--scaling weak|strong]
+
+`--config` picks one of BASELINE.json's configurations (scene, resolution, depth; default 2 = the headline one);
+`--steps` defaults to the config's spp.  `--scaling strong` keeps the config's frame fixed and cuts it into N tiles
+(configs 4 and 5 are quoted that way: one 3840x2160 / 1920x1080 frame over the 8 GPUs of a node); the default for
+N > 1 is weak scaling (every rank renders ~1920x1080 pixels of a frame that grows with N).
 
 One *step* = one iteration (1 sample per pixel) of the hot path over the whole frame: camera rays, up to
 `depth` bounce launches (intersect + shade + compaction), framebuffer accumulate.  At N=1 the workload is
@@ -31,17 +36,35 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MI
 VALU_PEAK_TFLOPS = 157.3  # fp32 vector peak (FMA = 2 flops), same guide / SURVEY 8(d)
 
 
+# BASELINE.json `configs`, in order.  spp = the ITERATIONS the config is quoted with (= default --steps).
+CONFIGS = {
+    1: dict(scene="sampleScene.txt", width=400, height=400, depth=4, spp=1, lobes="diffuse",
+            note="configs[0]: the reference's own CPU-runnable case (parity config)"),
+    2: dict(scene="sampleScene_spec.txt", width=1920, height=1080, depth=8, spp=256, lobes="diffuse+specular",
+            note="configs[1]: the configuration `metric` is quoted on"),
+    3: dict(scene="cornell_glass.txt", width=1920, height=1080, depth=16, spp=1024, lobes="diffuse+refraction", rotat="degrees",
+            note="configs[2]: Cornell box with glass sphere"),
+    4: dict(scene="sampleScene_spec.txt", width=3840, height=2160, depth=8, spp=512, lobes="diffuse+specular",
+            note="configs[3]: one 3840x2160 frame, pixel-tiled over the GPUs (use --scaling strong for N > 1)"),
+    5: dict(scene="cloud256.txt", width=1920, height=1080, depth=32, spp=4096, lobes="diffuse+specular+refraction", rotat="degrees",
+            note="configs[4]: 256-primitive cloud, compaction / divergence stress (use --scaling strong for N > 1)"),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (default 2)")
+    ap.add_argument("--steps", type=int, default=None, help="iterations timed (default: the config's spp, at most 4096)")
     ap.add_argument("--warmup", type=int, default=256)      # 50 ms: the GPU clock needs that long to settle (16: -3.5 %)
-    ap.add_argument("--scene", default="sampleScene_spec.txt")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = ~1920x1080 pixels per rank of a frame that grows with N; strong = the config's frame cut into N tiles")
+    ap.add_argument("--scene", default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--rr-start", type=int, default=-1)
-    ap.add_argument("--rotat", choices=["radians", "degrees"], default="radians")
+    ap.add_argument("--rotat", choices=["radians", "degrees"], default=None)
     ap.add_argument("--workgroup", type=int, default=0)
     ap.add_argument("--geom-path", type=int, default=0)
     ap.add_argument("--no-compaction", action="store_true")
@@ -53,46 +76,61 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
-                    help="PMC-derived HBM bytes per launch (written by profiles/collect_pmc.py), if present")
-    return ap.parse_args()
+                    help="PMC-derived HBM bytes per launch per config (written from profiles/collect_pmc.py summaries), if present")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    args.custom = any(v is not None for v in (args.scene, args.width, args.height, args.depth, args.rotat))
+    args.scene = args.scene or cfg["scene"]
+    args.width = args.width or cfg["width"]
+    args.height = args.height or cfg["height"]
+    args.depth = args.depth or cfg["depth"]
+    args.rotat = args.rotat or cfg.get("rotat", "radians")
+    if args.steps is None:
+        args.steps = cfg["spp"]
+    return args
 
 
 def cpu_baseline(args, scene_path, rotat):
-    """Oracle (kind 'port') on all host cores, bounded sample: full frame, as many spp as fit ~cpu-seconds."""
+    """Oracle (kind 'port') on the host cores, bounded sample of the same workload: the config's frame at as many spp as
+    fit ~cpu-seconds; a frame the oracle cannot finish once in that time is sampled at 1/2, 1/4 ... of the resolution
+    (same scene, camera, depth: the ray-bounce rate does not depend on the pixel count)."""
     import numpy as np  # noqa: F401
     import oracle_lib as O
     O.build()
-    sc = O.LoadedScene(scene_path, rotat)
-    sc.set_resolution(args.width, args.height)
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("PT_BENCH_CPU_THREADS", "16"))))   # a 1-GPU box's CPU share
-    # calibration pass on a strip of rows (same scene, same depth) to size the sample
-    t0 = time.perf_counter()
-    sc_small = O.LoadedScene(scene_path, rotat)
-    sc_small.set_resolution(args.width // 4, args.height // 4)
-    _, live = O.render(sc_small.geoms, sc_small.n_objects, sc_small.mats, sc_small.n_materials, sc_small.camera,
-                       args.depth, iters=1, rr_start=args.rr_start, nthreads=cores, direct_light=1 if args.direct_light else 0)
-    dt = time.perf_counter() - t0
-    est_full = dt * 16.0
-    spp = max(1, min(64, int(args.cpu_seconds / max(est_full, 1e-3))))
-    t0 = time.perf_counter()
-    _, live = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, args.depth, iters=spp,
-                       rr_start=args.rr_start, nthreads=cores, direct_light=1 if args.direct_light else 0)
-    dt = time.perf_counter() - t0
-    rb = int(live.sum())
-    # per-core figure (SURVEY 8(d)): the quarter-resolution frame on one thread
-    t1 = time.perf_counter()
-    _, live1 = O.render(sc_small.geoms, sc_small.n_objects, sc_small.mats, sc_small.n_materials, sc_small.camera,
-                        args.depth, iters=1, rr_start=args.rr_start, nthreads=1, direct_light=1 if args.direct_light else 0)
-    dt1 = time.perf_counter() - t1
+    if os.environ.get("PT_BENCH_CPU_THREADS"):
+        cores = max(1, min(cores, int(os.environ["PT_BENCH_CPU_THREADS"])))
+    dl = 1 if args.direct_light else 0
+
+    def run(w, h, spp, threads):
+        sc = O.LoadedScene(scene_path, rotat)
+        sc.set_resolution(w, h)
+        t0 = time.perf_counter()
+        _, live = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, args.depth, iters=spp,
+                           rr_start=args.rr_start, nthreads=threads, direct_light=dl)
+        return int(live.sum()), time.perf_counter() - t0
+
+    # calibration on 1/64 of the pixels
+    cw, ch = max(16, args.width // 8), max(16, args.height // 8)
+    rb_c, dt_c = run(cw, ch, 1, cores)
+    per_px = dt_c / (cw * ch)
+    scale = 1
+    while per_px * (args.width // scale) * (args.height // scale) > args.cpu_seconds and scale < 8:
+        scale *= 2
+    w, h = max(16, args.width // scale), max(16, args.height // scale)
+    spp = max(1, min(64, args.steps, int(args.cpu_seconds / max(per_px * w * h, 1e-4))))
+    rb, dt = run(w, h, spp, cores)
+    # per-core figure (SURVEY 8(d)): the calibration frame on one thread
+    rb1, dt1 = run(cw, ch, 1, 1)
     return {"value": rb / dt / 1e6, "unit": "Mray-bounces/s", "cores": cores, "kind": "port",
-            "single_thread": int(live1.sum()) / dt1 / 1e6,
-            "sample": f"{args.width}x{args.height} x {spp} spp x {args.depth} bounces of the same scene "
+            "single_thread": rb1 / dt1 / 1e6,
+            "sample": f"{w}x{h} x {spp} spp x {args.depth} bounces of the same scene and camera"
+                      f"{'' if scale == 1 else f' (1/{scale} of the resolution)'} "
                       f"({rb} ray-bounces in {dt:.2f} s, oracle/pt_oracle.c, {cores} threads)",
-            "ms_per_frame": dt / spp * 1e3}
+            "ms_per_frame": dt / spp * 1e3 * scale * scale}
 
 
 def main():
@@ -133,7 +171,10 @@ def main():
     # weak scaling: the frame grows with the GPU count at fixed aspect and camera (N=4 is BASELINE configs[3]'s
     # 3840x2160), so every rank owns a band of ~1920*1080 pixels of the same picture
     from project3_pathtracer_amd import sharding
-    W, Hfull = sharding.weak_scaled_frame(args.width, args.height, world)
+    if args.scaling == "strong" or world == 1:
+        W, Hfull = args.width, args.height           # the config's own frame, cut into `world` tiles
+    else:
+        W, Hfull = sharding.weak_scaled_frame(args.width, args.height, world)
     sc.set_resolution(W, Hfull)
     # N>1: interleaved 8-row strips (strip k -> rank k % N) so that every rank sees the same mix of ceiling, walls
     # and floor; --bands switches to one contiguous band per rank (up to ~9 % slower at N=8: the bands differ in
@@ -148,6 +189,7 @@ def main():
         Hmax = sharding.max_band_rows(Hfull, world)
 
     fb = torch.zeros((Hmax, W, 3), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)      # the zero-fill ran on torch's stream, the renderer has its own
     r = pkg.Renderer(dev_index)
     r.set_options(depth=args.depth, rr_start=args.rr_start, workgroup=args.workgroup, geom_path=args.geom_path,
                   compaction=0 if args.no_compaction else args.compaction, batch=args.batch, use_graph=0 if args.no_graph else 1,
@@ -213,7 +255,10 @@ def main():
         npix = W * Hband
         alg_bytes = pkg.algorithmic_bytes(npix, live_in, args.steps)      # this rank, the timed K steps
         # dominant kernel: k_bounce, one HIP event pair per launch on the render stream (a few extra steps)
-        prof_steps = args.batch or 16          # one full batch: the same launch shape as the timed region
+        lib_batch = args.batch or 16
+        nb_timed = (args.steps + lib_batch - 1) // lib_batch
+        timed_batches = [args.steps // nb_timed + (1 if j < args.steps % nb_timed else 0) for j in range(nb_timed)]
+        prof_steps = timed_batches[0]          # one batch of the timed region's size: the same launch shape
         r.reset_stats()
         bounce_ms = r.render_profiled(first + args.steps, prof_steps)
         pst = r.stats()
@@ -222,11 +267,15 @@ def main():
         p_ms = sum(bounce_ms)
         launches = int(pst.bounce_launches)      # one launch carries `batch` iterations of one bounce
         achieved = p_bytes / (p_ms * 1e-3) / 1e9
-        traffic = None
-        if os.path.exists(args.traffic_json):
+        # HBM bytes per launch from the PMC counters cannot be collected inside this run (rocprofv3 --pmc, one pass per
+        # counter group): the figure is the STORED result of the last collection for this config (profiles/collect_pmc.py)
+        traffic, traffic_source = None, None
+        if os.path.exists(args.traffic_json) and not args.custom and world == 1:
             try:
                 with open(args.traffic_json) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
+                    ent = json.load(f).get(f"config{args.config}")
+                if ent:
+                    traffic, traffic_source = ent.get("hbm_bytes_per_launch"), "stored: " + str(ent.get("source"))
             except Exception:
                 traffic = None
         tile_note = ", interleaved 8-row strips" if strips else ""
@@ -239,16 +288,17 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.scene} {W}x{Hfull} ({world} tile(s) of ~{W}x{Hmax} rows{tile_note}), {args.steps} spp, "
-                            f"{args.depth} bounces, diffuse+specular, rotat={args.rotat}, rr_start={args.rr_start}",
-                "scene": args.scene, "width": W, "height": Hfull, "depth": args.depth, "spp": args.steps,
+                "workload": f"BASELINE config {args.config}{' (modified)' if args.custom else ''}: {args.scene} {W}x{Hfull} "
+                            f"({world} tile(s) of ~{W}x{Hmax} rows{tile_note}), {args.steps} spp, "
+                            f"{args.depth} bounces, {CONFIGS[args.config]['lobes']}, rotat={args.rotat}, rr_start={args.rr_start}",
+                "baseline_config": args.config, "scene": args.scene, "width": W, "height": Hfull, "depth": args.depth, "spp": args.steps,
                 "rotat_units": args.rotat, "primitives": sc.n_objects, "materials": sc.n_materials,
-                "compaction": 0 if args.no_compaction else args.compaction, "iteration_batch": args.batch or 16, "hip_graph": not args.no_graph, "direct_light": bool(args.direct_light),
+                "compaction": 0 if args.no_compaction else args.compaction, "iteration_batch": lib_batch, "timed_batches": timed_batches, "hip_graph": not args.no_graph, "direct_light": bool(args.direct_light),
                 "parallelism": (f"pixel-strips x{world}" if strips else f"pixel-bands x{world}") + (", 1 RCCL gather" if world > 1 else ""),
             },
             "ray_bounces": int(rb_total),
@@ -267,6 +317,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "bytes_per_launch": p_bytes / launches,
                 "avg_launch_ms": p_ms / launches,
                 "launches_measured": launches,

@@ -81,7 +81,7 @@ typedef struct pt_options {
     int depth;            /* bounces per path, 1..PT_MAX_DEPTH (default 8) */
     int rr_start;         /* first bounce with Russian roulette, <0 = off (default -1) */
     unsigned seed;        /* RNG stream selector (default 0) */
-    int compaction;       /* live-ray compaction after every bounce: 1 = per-wave reservation in 8 pool segments, no
+    int compaction;       /* live-ray compaction after every bounce: 1 = per-wave reservation in 32 pool segments, no
                              barrier (default); 2 = workgroup LDS scan + one counter; 0 = off, rays keep their slot */
     int workgroup;        /* threads per workgroup: 64, 128, 256, 512 or 1024 (default 0 = library choice) */
     int geom_path;        /* how primitives reach the lanes: 0 = library choice (default: 5 up to 40 primitives, else 6),

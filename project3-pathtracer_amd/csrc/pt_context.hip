@@ -17,10 +17,10 @@
 #include "pt_internal.h"
 
 namespace {
-
 thread_local std::string g_last_error;
+}
 
-int fail(int code, const char *fmt, ...)
+int pt::fail(int code, const char *fmt, ...)
 {
     char buf[512];
     va_list ap;
@@ -30,6 +30,10 @@ int fail(int code, const char *fmt, ...)
     g_last_error = buf;
     return code;
 }
+
+namespace {
+
+using pt::fail;
 
 #define HIP_TRY(expr)                                                                                  \
     do {                                                                                               \
@@ -84,8 +88,8 @@ struct pt_ctx {
     pt::IterState *d_state = nullptr;
     bool image_valid = false;   // framebuffer holds iterations 1..k of the current frame
 
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph = nullptr;          // one batch (bookkeeping, depth bounce launches, accumulate); the batch's
+    hipGraphExec_t graph_exec = nullptr; //   iteration count lives on the device, so this graph serves every pt_render
 
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timers;
     double gpu_ms = 0.0;
@@ -533,12 +537,6 @@ int configure(pt_ctx *c)
     cfg.nee = k.nlights > 0 ? 1 : 0;             // no lights: nothing to sample, the plain kernels are exact
     k.cull = (k.nG > 32 && !getenv("PT_NO_CULL")) ? 1 : 0;
     k.nshard = (cfg.compact == 1) ? pt::NSHARD : 1;
-    // Ray prefetch (LDS-DMA, 2.5 KiB of LDS per wave) is built but off: with the scalar chunk bookkeeping in place it
-    // is neutral at equal occupancy (33.3 vs 34.0 G at 5 workgroups/CU) and its LDS keeps the kernel from the 6
-    // workgroups/CU where it runs best.  PT_PREFETCH=1 turns it on for experiments (never past the ~31 KiB mark where a
-    // fifth workgroup stops fitting although the occupancy query still counts it).
-    k.prefetch = getenv("PT_PREFETCH") ? atoi(getenv("PT_PREFETCH")) : 0;
-    if (k.prefetch && pt::bounce_lds_bytes(k, cfg) > 31 * 1024) k.prefetch = 0;
     size_t lds = pt::bounce_lds_bytes(k, cfg);
     if (lds > 160 * 1024 && o.geom_path == 0) {
         // the hierarchy (32 B per node, 2 nodes per primitive) no longer fits the CU's LDS: fall back to the scalar
@@ -624,20 +622,29 @@ int configure(pt_ctx *c)
     return PT_OK;
 }
 
-// one launch sequence = `nslot` consecutive iterations: bookkeeping, depth bounce launches, accumulate.
+// one launch sequence = one batch of consecutive iterations (their number is device state, IterState::nslot):
+// bookkeeping, depth bounce launches, accumulate.
 // ev (optional): 2*depth events recorded around the bounce launches (pt_render_profiled).
-int enqueue_batch(pt_ctx *c, hipStream_t s, int nslot, hipEvent_t *ev)
+int enqueue_batch(pt_ctx *c, hipStream_t s, hipEvent_t *ev)
 {
-    pt::KParams kp = c->kp;
-    kp.nslot = nslot;
-    HIP_TRY(pt::launch_iter_begin(s, c->d_state, (long long)kp.npix * nslot, kp.depth, c->cfg.compact, c->batch, nslot));
+    const pt::KParams &kp = c->kp;
+    HIP_TRY(pt::launch_iter_begin(s, c->d_state, kp.npix, kp.depth, c->cfg.compact));
     for (int b = 0; b < kp.depth; ++b) {
         if (ev) HIP_TRY(hipEventRecord(ev[2 * b], s));
         HIP_TRY(pt::launch_bounce(s, kp, c->cfg, b));
         if (ev) HIP_TRY(hipEventRecord(ev[2 * b + 1], s));
     }
-    HIP_TRY(pt::launch_accumulate(s, kp.image, kp.lbuf, c->d_state, kp.npix, nslot));
+    HIP_TRY(pt::launch_accumulate(s, kp.image, kp.lbuf, c->d_state, kp.npix));
     return PT_OK;
+}
+
+// iter_count iterations as near-equal batches of at most `batch`: n batches of q, the first r of them one more
+// (20 iterations at batch 16 -> 10 + 10, not 16 + 4: a launch that carries 4 iterations pays the same fixed cost)
+void batch_schedule(int iter_count, int batch, int *n, int *q, int *r)
+{
+    *n = (iter_count + batch - 1) / batch;
+    *q = iter_count / *n;
+    *r = iter_count % *n;
 }
 
 }  // namespace
@@ -893,27 +900,25 @@ int pt_render(pt_ctx *c, int iter_first, int iter_count)
     c->timers.emplace_back(e0, e1);
     HIP_TRY(hipEventRecord(e0, s));
 
-    // st->iter holds the first iteration of the running batch; every k_iter_begin advances it by one full batch
-    const int B = c->batch;
-    const int full = iter_count / B, rem = iter_count % B;
-    HIP_TRY(pt::launch_iter_set(s, c->d_state, (uint32_t)(iter_first - B)));
-    if (c->opt.use_graph && full > 0) {
+    int nb, q, r;
+    batch_schedule(iter_count, c->batch, &nb, &q, &r);
+    HIP_TRY(pt::launch_iter_set(s, c->d_state, (uint32_t)iter_first, (uint32_t)q, (uint32_t)r));
+    if (c->opt.use_graph) {
         if (!c->graph_exec) {
             HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            rc = enqueue_batch(c, s, B, nullptr);
+            rc = enqueue_batch(c, s, nullptr);
             hipError_t ce = hipStreamEndCapture(s, &c->graph);
             if (rc != PT_OK) { drop_graph(c); return rc; }
             if (ce != hipSuccess) { drop_graph(c); return fail(PT_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce)); }
             HIP_TRY(hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
         }
-        for (int i = 0; i < full; ++i) HIP_TRY(hipGraphLaunch(c->graph_exec, s));
+        for (int i = 0; i < nb; ++i) HIP_TRY(hipGraphLaunch(c->graph_exec, s));
     } else {
-        for (int i = 0; i < full; ++i) { rc = enqueue_batch(c, s, B, nullptr); if (rc != PT_OK) return rc; }
+        for (int i = 0; i < nb; ++i) { rc = enqueue_batch(c, s, nullptr); if (rc != PT_OK) return rc; }
     }
-    if (rem > 0) { rc = enqueue_batch(c, s, rem, nullptr); if (rc != PT_OK) return rc; }
     HIP_TRY(pt::launch_iter_fold(s, c->d_state, c->kp.depth));
     HIP_TRY(hipEventRecord(e1, s));
-    c->bounce_launches += (unsigned long long)(full + (rem ? 1 : 0)) * (unsigned long long)c->kp.depth;
+    c->bounce_launches += (unsigned long long)nb * (unsigned long long)c->kp.depth;
     c->image_valid = true;
     return PT_OK;
 }
@@ -932,12 +937,12 @@ int pt_render_profiled(pt_ctx *c, int iter_first, int iter_count, double *bounce
     // no system-scope fence at the events: a default event makes every kernel end with an L2 write-back and start with
     // a cold cache, which showed up as +12 % on the launches bracketed this way
     for (auto &e : ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
-    const int B = c->batch;
-    HIP_TRY(pt::launch_iter_set(s, c->d_state, (uint32_t)(iter_first - B)));
+    int nb, q, r;
+    batch_schedule(iter_count, c->batch, &nb, &q, &r);
+    HIP_TRY(pt::launch_iter_set(s, c->d_state, (uint32_t)iter_first, (uint32_t)q, (uint32_t)r));
     int launches = 0;
-    for (int done = 0; done < iter_count; done += B) {
-        const int nslot = (iter_count - done) < B ? (iter_count - done) : B;
-        rc = enqueue_batch(c, s, nslot, ev.data());
+    for (int i = 0; i < nb; ++i) {
+        rc = enqueue_batch(c, s, ev.data());
         if (rc != PT_OK) return rc;
         launches++;
         HIP_TRY(hipStreamSynchronize(s));

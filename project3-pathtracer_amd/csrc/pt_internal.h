@@ -30,8 +30,13 @@ static constexpr int CNT_STRIDE = 32;            // uint32 per counter slot = 12
 __host__ __device__ constexpr int cnt_index(int bounce, int shard) { return (bounce * NSHARD + shard) * CNT_STRIDE; }
 
 struct IterState {
-    uint32_t iter;                               // iteration being rendered (1-based, ref: src/main.cpp:95)
-    uint32_t pad[31];
+    uint32_t iter;                               // first iteration of the running batch (1-based, ref: src/main.cpp:95)
+    // Batch schedule of the running pt_render call, kept on the device so that ONE captured hipGraph serves every
+    // iteration count: the call's iterations are cut into `sched_n` batches of sched_q (+1 for the first sched_r)
+    // iterations; k_iter_begin advances `iter` by the previous batch and sets `nslot` for the one that starts.
+    uint32_t nslot;                              // iterations in flight in the running batch (1..PT_MAX_BATCH)
+    uint32_t sched_q, sched_r, sched_j;          // batch size, batches that carry one more, index of the next batch
+    uint32_t pad[27];
     uint32_t counts[(PT_MAX_DEPTH + 1) * NSHARD * CNT_STRIDE];   // live rays entering bounce b, per segment
     unsigned long long live_in[PT_MAX_DEPTH];    // summed over segments and iterations (stats)
     unsigned long long iterations;
@@ -59,7 +64,6 @@ struct KParams {
     int nnodes;
     int nbig;              // primitives too large to cull (walls...): tested by every ray before the walk
     int big[16];           // their indices
-    int prefetch;          // 1 = later bounces of the pair-queue path prefetch their rays into LDS (decided by the host)
     const float *face_n;   // per primitive: 8 float4, entry `face code` = world normal of that box face (boxNormal's result)
     const float *ro_eye;   // per primitive: inverseTransform*(eye,1) as float4 (camera rays share their origin)
     int eye_cull;          // 1 = camera-ray waves skip primitives outside their boxes (box_eye), ablation switch
@@ -68,7 +72,7 @@ struct KParams {
     const float *mats;     // M_PLANES planes of nM floats
     float *image;          // tile framebuffer, fp32 RGB packed (12 B/pixel)
     int cull;              // 1 = skip primitives whose bounding sphere no lane of the wave can hit (large scenes)
-    int nslot;             // iterations in flight in this launch sequence (1..PT_MAX_BATCH)
+    int nslot;             // most iterations in flight per launch sequence (1..PT_MAX_BATCH); a batch's own count is IterState::nslot
     float *lbuf;           // nslot planes of npix fp32 RGB radiance samples, folded into `image` by k_accumulate
     int nshard;            // pool segments in use: NSHARD (compaction 1), 1 otherwise
     uint32_t segcap;       // slots per pool segment
@@ -95,14 +99,17 @@ struct LaunchCfg {
 };
 
 // kernels (pt_kernels.hip)
-hipError_t launch_iter_set(hipStream_t s, IterState *st, uint32_t value);
-hipError_t launch_iter_begin(hipStream_t s, IterState *st, long long nrays, int depth, int compact, int step, int nslot);
-hipError_t launch_accumulate(hipStream_t s, float *image, const float *lbuf, const IterState *st, int npix, int nslot);
+hipError_t launch_iter_set(hipStream_t s, IterState *st, uint32_t iter_first, uint32_t q, uint32_t r);
+hipError_t launch_iter_begin(hipStream_t s, IterState *st, int npix, int depth, int compact);
+hipError_t launch_accumulate(hipStream_t s, float *image, const float *lbuf, const IterState *st, int npix);
 hipError_t launch_iter_fold(hipStream_t s, IterState *st, int depth);
 hipError_t launch_bounce(hipStream_t s, const KParams &p, const LaunchCfg &cfg, int bounce);
 hipError_t launch_send_image_to_pbo(hipStream_t s, pt_uchar4 *pbo, const float *image, int npix);
 hipError_t launch_selftest_math(hipStream_t s, unsigned long long *out3);
 hipError_t launch_device_kat(hipStream_t s, int op, const float *in, float *out, int n_out);
+// error reporting shared by the C-ABI translation units: records the message behind pt_last_error(), returns `code`
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
 size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg);
 int bounce_max_blocks_per_cu(const KParams &p, const LaunchCfg &cfg);
 

@@ -8,11 +8,11 @@
 //   k_iter_*               iteration bookkeeping (live-ray counters, stats) kept on the device so that one
 //                          hipGraph can be replayed per iteration
 //
-// Execution model (wave64): one lane = one live ray, up to 8 iterations in flight per launch.  The nearest-hit
+// Execution model (wave64): one lane = one live ray, up to 16 iterations in flight per launch.  The nearest-hit
 // search comes in six interchangeable forms (GEOM_*, below); the default ones first run a cheap per-lane box
 // pre-test and then do the exact intersection work on full 64-wide batches of (ray, primitive) pairs drawn
 // from a wave-private LDS queue.  Rays live in SoA pools (pt_internal.h RayPool); survivors of a bounce are
-// written densely into the other pool: wave ballot + v_mbcnt prefix and ONE atomic per wave on one of 8
+// written densely into the other pool: wave ballot + v_mbcnt prefix and ONE atomic per wave on one of 32
 // sharded counters (no workgroup barrier).  Results do not depend on the order rays land in the pool because
 // every RNG stream is keyed on (global pixel, iteration, bounce).  DESIGN.md section 5 has the measurements.
 //
@@ -25,16 +25,6 @@ namespace pt {
 using namespace ptd;
 
 static constexpr uint32_t DEAD = 0xFFFFFFFFu;
-// Ray prefetch by LDS-DMA (later bounces of the pair-queue path).  Measured on config 2: a chunk's wave latency falls by
-// 19 % (the top-of-chunk wait, 35 % of it, was mostly for the acknowledgement of the wave's own previous stores: vmcnt
-// counts loads and stores together), throughput moves +1 % (+6 % with axis-aligned walls): the kernel is VALU-issue-
-// bound and the resident waves already cover most of the wait.  Not used by the large-scene path, where its 10 KiB of
-// LDS cost a workgroup per CU (-15 %).
-#ifndef PT_RAY_PREFETCH
-#define PT_RAY_PREFETCH 1
-#endif
-static constexpr uint32_t RAY_PENDING = 0xFFFFFFFFu;   // pixel word of a prefetch slot whose record has not landed yet
-static constexpr int RAY_LDS_BYTES = 2560;        // one wave's 64 prefetched ray records (40 B each)
 static constexpr bool DEBUG_CULL = false;
 static constexpr bool DEBUG_PAIR = false;
 static constexpr bool DEBUG_PHASE = false;       // per-wave shader-clock stamps between the phases of a chunk -> IterState::dbg
@@ -795,15 +785,6 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
     float *s_mats = reinterpret_cast<float *>(s_queue + queue_bytes);
     const int mat_words = (p.nM * M_PLANES + 3) & ~3;
     uint32_t *s_scan = reinterpret_cast<uint32_t *>(s_mats + mat_words);   // [2][NW] wave totals, [2] bases
-    constexpr bool PREFETCH_BUILT = PT_RAY_PREFETCH && GEOM == GEOM_PAIR && !FIRST && COMPACT != 0;
-    const bool PREFETCH = PREFETCH_BUILT && p.prefetch != 0;      // the host turns it off when its LDS would cost a workgroup per CU
-    constexpr int SCAN_WORDS = (2 * NW + 2 + 3) & ~3;
-    unsigned char *const s_ray = reinterpret_cast<unsigned char *>(s_scan + SCAN_WORDS) + (threadIdx.x >> 6) * RAY_LDS_BYTES;   // [a 1024][b 1024][c.x 256][c.y 256]
-    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
-    lds_vu32 *const s_ray_pix = (lds_vu32 *)(__attribute__((address_space(3))) unsigned char *)(s_ray + 2304);
-    const uint32_t s_ray_lds = (uint32_t)__builtin_amdgcn_readfirstlane(
-        (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_ray);     // LDS byte address, wave-uniform
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: chunk bookkeeping runs on the scalar unit
@@ -867,7 +848,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
     __shared__ uint32_t s_segn[NSHARD];
     if (tid < NSHARD) {
         uint32_t ns = 0;
-        if (FIRST || COMPACT == 0) ns = (tid == 0) ? (uint32_t)p.npix * (uint32_t)p.nslot : 0u;
+        if (FIRST || COMPACT == 0) ns = (tid == 0) ? (uint32_t)p.npix * st->nslot : 0u;
         else if (tid < p.nshard) ns = st->counts[cnt_index(bounce, tid)];
         s_segn[tid] = ns;
     }
@@ -898,35 +879,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
         slot_i = cu.sh * p.segcap + idx;                          // pool slot (FIRST / COMPACT 0: sh == 0, i == idx)
         return chunk < total_chunks && idx < cu.nseg;
     };
-    Cursor cur = {0u, 0u, (uint32_t)__builtin_amdgcn_readfirstlane((int)s_segn[0])}, nxt = cur;
-    // Ray prefetch (later bounces): the NEXT chunk's records travel pool -> LDS by LDS-DMA (global_load_lds: no VGPR
-    // destination, lane-linear image = exactly the SoA pool layout) while this chunk is being traced, so a wave does not
-    // sit out the pool's read latency at the top of every chunk (measured: 35 % of a chunk's wave latency).
-    auto prefetch = [&](uint32_t R2) {
-        uint32_t j;
-        // arrival is detected through LDS itself (a sentinel in the pixel-word plane, the last piece to land: no live
-        // ray has an all-ones pixel word), not through vmcnt: that counter also holds this wave's outstanding STORES,
-        // and waiting for those costs thousands of cycles per chunk
-        s_ray_pix[lane] = RAY_PENDING;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (locate(nxt, R2, j)) {
-            // inline asm: hipcc orders every later LDS access behind a builtin LDS-DMA with s_waitcnt vmcnt(0) -- which
-            // would also wait for this wave's outstanding stores, the very thing to avoid.  M0 = wave-uniform LDS byte
-            // address of the destination, written in the statement that uses it.
-            unsigned keep;
-            const float4 *ga = in.a + j, *gb = in.b + j;
-            const float *gc = reinterpret_cast<const float *>(in.c + j);
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(ga), "s"(s_ray_lds) : "memory");
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(gb), "s"(s_ray_lds + 1024u) : "memory");
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(gc), "s"(s_ray_lds + 2048u) : "memory");
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(gc + 1), "s"(s_ray_lds + 2304u) : "memory");
-        }
-    };
-    if (PREFETCH) prefetch(blockIdx.x);
+    Cursor cur = {0u, 0u, (uint32_t)__builtin_amdgcn_readfirstlane((int)s_segn[0])};
     for (uint32_t R = blockIdx.x; R * NW < total_chunks; R += gridDim.x, ++round) {     // workgroup-uniform trip count
         const unsigned long long tc0 = DEBUG_PHASE ? __builtin_amdgcn_s_memtime() : 0ull;
         uint32_t i;
@@ -985,23 +938,6 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
                     d = normalize(Pf - o);
                 }
             }
-        } else if (PREFETCH) {
-            for (;;) {                                                  // this chunk's records have landed in LDS
-                pix = s_ray_pix[lane];
-                if (__ballot(valid && pix == RAY_PENDING) == 0ull) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            asm volatile("" ::: "memory");
-            if (valid) {
-                const float4 a = reinterpret_cast<const float4 *>(s_ray)[lane];
-                const float4 b = reinterpret_cast<const float4 *>(s_ray + 1024)[lane];
-                const float cx = reinterpret_cast<const float *>(s_ray + 2048)[lane];
-                o = mk(a.x, a.y, a.z);
-                d = mk(a.w, b.x, b.y);
-                T = mk(b.z, b.w, cx);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // ... and are in registers: the slot is free again
-            prefetch(R + gridDim.x);
         } else {
             if (valid) {
                 const float2 c = in.c[i];
@@ -1355,38 +1291,57 @@ hipError_t launch_selftest_math(hipStream_t s, unsigned long long *out)
 // ---------------------------------------------------------------------------------------------
 // iteration bookkeeping
 // ---------------------------------------------------------------------------------------------
-__global__ void k_iter_set(IterState *st, uint32_t value) { st->iter = value; }
+// starts a pt_render call: first iteration and the batch schedule (q iterations per batch, the first r batches one more)
+__global__ void k_iter_set(IterState *st, uint32_t iter_first, uint32_t q, uint32_t r)
+{
+    st->iter = iter_first;
+    st->nslot = 0u;
+    st->sched_q = q;
+    st->sched_r = r;
+    st->sched_j = 0u;
+}
 
-// fold the previous iteration's per-bounce live counts into the stats, reset them, advance the iteration
-// starts a batch of `nslot` iterations: fold the previous batch's counters, reset them, advance the iteration
-// counter by `step` (the size of the previous batch; st->iter is the first iteration of the current batch)
-__global__ void k_iter_begin(IterState *st, uint32_t nrays, int depth, int compact, uint32_t step, uint32_t nslot)
+// starts a batch: fold the previous batch's per-bounce live counts into the stats, reset them, advance the iteration
+// counter past the previous batch and publish this batch's iteration count (st->iter = first iteration of the batch)
+__global__ void k_iter_begin(IterState *st, uint32_t npix, int depth, int compact)
 {
     const int b = threadIdx.x;
+    const uint32_t prev = st->nslot, j = st->sched_j;
+    const uint32_t nslot = st->sched_q + (j < st->sched_r ? 1u : 0u);
+    __syncthreads();                             // everyone has read the schedule before thread 0 moves it on
     if (b <= depth) {
         unsigned long long sum = 0;
         for (int sh = 0; sh < NSHARD; ++sh) {
             sum += st->counts[cnt_index(b, sh)];
-            st->counts[cnt_index(b, sh)] = (b == 0 && sh == 0 && compact) ? nrays : 0u;
+            st->counts[cnt_index(b, sh)] = (b == 0 && sh == 0 && compact) ? npix * nslot : 0u;
         }
         if (b < depth) st->live_in[b] += sum;
     }
-    if (b == 0) { st->iter += step; st->iterations += nslot; }
+    if (b == 0) {
+        st->iter += prev;
+        st->nslot = nslot;
+        st->sched_j = j + 1u;
+        st->iterations += nslot;
+    }
 }
 
 // Accumulation (DESIGN.md "Canonical semantics" 6): image = (image*(i-1) + L_i)/i for the batch's iterations in
 // order, one thread per pixel, streaming (the per-path samples were written to lbuf by k_bounce).
-__global__ __launch_bounds__(256) void k_accumulate(float *image, const float *lbuf, const IterState *st, int npix, int nslot)
+__global__ __launch_bounds__(256) void k_accumulate(float *image, const float *lbuf, const IterState *st, int npix)
 {
     const uint32_t iter0 = st->iter;
+    const int nslot = (int)st->nslot;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
         float r = image[3 * i], g = image[3 * i + 1], b = image[3 * i + 2];
         for (int k = 0; k < nslot; ++k) {
             const float *lp = lbuf + 3 * ((size_t)k * (size_t)npix + (size_t)i);
-            const float fi = (float)(iter0 + (uint32_t)k), fim1 = (float)(iter0 + (uint32_t)k - 1u);
-            r = (r * fim1 + lp[0]) / fi;
-            g = (g * fim1 + lp[1]) / fi;
-            b = (b * fim1 + lp[2]) / fi;
+            const uint32_t it = iter0 + (uint32_t)k;
+            const float fi = (float)it, fim1 = (float)(it - 1u);
+            // iteration 1 restarts the running mean: (old*0 + L)/1 == L for every finite old value, and taking L
+            // directly keeps a NaN / Inf left in a caller-owned buffer from surviving the restart
+            r = (it == 1u) ? lp[0] : (r * fim1 + lp[0]) / fi;
+            g = (it == 1u) ? lp[1] : (g * fim1 + lp[1]) / fi;
+            b = (it == 1u) ? lp[2] : (b * fim1 + lp[2]) / fi;
         }
         image[3 * i] = r;
         image[3 * i + 1] = g;
@@ -1437,7 +1392,6 @@ size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg)
     if (cfg.geom == GEOM_PAIR) prim += (size_t)p.nG * 32 * (cfg.nee ? 2 : 1);
     size_t mats = (size_t)((p.nM * M_PLANES + 3) & ~3) * sizeof(float);
     size_t scan = (size_t)((2 * (cfg.workgroup / 64) + 2 + 3) & ~3) * sizeof(uint32_t);
-    if (PT_RAY_PREFETCH && cfg.geom == GEOM_PAIR && cfg.compact != 0 && p.prefetch) scan += (size_t)(cfg.workgroup / 64) * RAY_LDS_BYTES;   // ray prefetch slots
     static const size_t extra = getenv("PT_EXTRA_LDS") ? (size_t)atol(getenv("PT_EXTRA_LDS")) : 0;   // occupancy experiments
     return prim + queue + mats + scan + extra;
 }
@@ -1512,25 +1466,24 @@ hipError_t launch_bounce(hipStream_t s, const KParams &p, const LaunchCfg &cfg, 
                            bounce_lds_bytes(p, cfg), s);
 }
 
-hipError_t launch_iter_set(hipStream_t s, IterState *st, uint32_t value)
+hipError_t launch_iter_set(hipStream_t s, IterState *st, uint32_t iter_first, uint32_t q, uint32_t r)
 {
-    hipLaunchKernelGGL(k_iter_set, dim3(1), dim3(1), 0, s, st, value);
+    hipLaunchKernelGGL(k_iter_set, dim3(1), dim3(1), 0, s, st, iter_first, q, r);
     return hipGetLastError();
 }
 
-hipError_t launch_iter_begin(hipStream_t s, IterState *st, long long nrays, int depth, int compact, int step, int nslot)
+hipError_t launch_iter_begin(hipStream_t s, IterState *st, int npix, int depth, int compact)
 {
-    hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(128), 0, s, st, (uint32_t)nrays, depth, compact != 0 ? 1 : 0,
-                       (uint32_t)step, (uint32_t)nslot);
+    hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(128), 0, s, st, (uint32_t)npix, depth, compact != 0 ? 1 : 0);
     return hipGetLastError();
 }
 
-hipError_t launch_accumulate(hipStream_t s, float *image, const float *lbuf, const IterState *st, int npix, int nslot)
+hipError_t launch_accumulate(hipStream_t s, float *image, const float *lbuf, const IterState *st, int npix)
 {
     int grid = (npix + 255) / 256;
     if (grid > 8192) grid = 8192;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(256), 0, s, image, lbuf, st, npix, nslot);
+    hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(256), 0, s, image, lbuf, st, npix);
     return hipGetLastError();
 }
 

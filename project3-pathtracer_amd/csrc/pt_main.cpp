@@ -22,6 +22,7 @@
 
 #include "pt_refstructs.h"
 #include "pt_scene.h"
+#include "pt_shim.h"
 
 using namespace std;
 
@@ -163,9 +164,14 @@ int main(int argc, char **argv)
          << (int)renderCam->resolution.x << "x" << (int)renderCam->resolution.y << ", " << renderCam->iterations
          << " iterations" << endl;
 
+    // This driver reads renderCam->image only when a frame's last iteration is done (as src/main.cpp:114-125 does), so
+    // the binding may render iterations in batches and skip the per-call image copy; the environment still overrides.
+    pt_shim_configure(getenv("PT_SHIM_BATCH") ? atoi(getenv("PT_SHIM_BATCH")) : 16,
+                      getenv("PT_READBACK_EVERY") ? atoi(getenv("PT_READBACK_EVERY")) : 0);
     const auto t0 = chrono::steady_clock::now();
     long long calls = 0;
     while (runCuda()) calls++;
+    pt_shim_flush();
     const double sec = chrono::duration<double>(chrono::steady_clock::now() - t0).count();
     cout << "Done: " << calls << " driver passes in " << sec << " s" << endl;
     return 0;

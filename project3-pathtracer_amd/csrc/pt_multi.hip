@@ -14,7 +14,7 @@
 
 #include <vector>
 
-#include "../../include/pt_abi.h"
+#include "pt_internal.h"
 
 struct pt_multi {
     std::vector<pt_ctx *> ctx;
@@ -62,7 +62,7 @@ int copy_strips(pt_multi *m, float *host_frame, void *device_frame, int dst_devi
         void *tile = nullptr;
         rc = pt_image_device_pointer(m->ctx[(size_t)k], &tile);
         if (rc != PT_OK) return rc;
-        if (hipSetDevice(m->device[(size_t)k]) != hipSuccess) return PT_ERR_HIP;
+        if (hipSetDevice(m->device[(size_t)k]) != hipSuccess) return pt::fail(PT_ERR_HIP, "copy_strips: %s", hipGetErrorString(hipGetLastError()));
         const int nstrips = (H + S - 1) / S;
         int full = 0, tail_rows = 0, tail_strip = -1;
         for (int j = k; j < nstrips; j += n) {
@@ -80,7 +80,7 @@ int copy_strips(pt_multi *m, float *host_frame, void *device_frame, int dst_devi
             char *ft = frame + (size_t)tail_strip * stripb, *tt = (char *)tile + (size_t)full * stripb;
             e = to_frame ? hipMemcpy(ft, tt, rowb * (size_t)tail_rows, kind) : hipMemcpy(tt, ft, rowb * (size_t)tail_rows, kind);
         }
-        if (e != hipSuccess) return PT_ERR_HIP;
+        if (e != hipSuccess) return pt::fail(PT_ERR_HIP, "copy_strips: %s", hipGetErrorString(e));
         (void)dst_device;
     }
     return PT_OK;
@@ -91,7 +91,7 @@ extern "C" {
 
 int pt_multi_create(const int *devices, int n, pt_multi **out)
 {
-    if (!devices || n < 1 || n > 64 || !out) return PT_ERR_INVALID;
+    if (!devices || n < 1 || n > 64 || !out) return pt::fail(PT_ERR_INVALID, "pt_multi_create: invalid argument or state");
     *out = nullptr;
     pt_multi *m = new pt_multi();
     pt_default_options(&m->opt);
@@ -123,23 +123,23 @@ int pt_multi_count(const pt_multi *m) { return m ? (int)m->ctx.size() : 0; }
 // lengths vary down the frame); 0: one contiguous band per device (default)
 int pt_multi_set_strips(pt_multi *m, int strip_rows)
 {
-    if (!m || strip_rows < 0) return PT_ERR_INVALID;
+    if (!m || strip_rows < 0) return pt::fail(PT_ERR_INVALID, "pt_multi_set_strips: invalid argument or state");
     if (strip_rows > 0 && m->have_cam && (long long)strip_rows * (long long)m->ctx.size() > (long long)m->height + strip_rows - 1)
-        return PT_ERR_INVALID;                     // some device would own no strip
+        return pt::fail(PT_ERR_INVALID, "pt_multi_set_strips: invalid argument or state");                     // some device would own no strip
     m->strip = strip_rows;
     return apply_options(m);
 }
 
 int pt_multi_set_options(pt_multi *m, const pt_options *o)
 {
-    if (!m || !o) return PT_ERR_INVALID;
+    if (!m || !o) return pt::fail(PT_ERR_INVALID, "pt_multi_set_options: invalid argument or state");
     m->opt = *o;
     return apply_options(m);
 }
 
 int pt_multi_set_scene(pt_multi *m, const pt_static_geom *geoms, int nG, const pt_material *mats, int nM)
 {
-    if (!m) return PT_ERR_INVALID;
+    if (!m) return pt::fail(PT_ERR_INVALID, "pt_multi_set_scene: invalid argument or state");
     for (pt_ctx *c : m->ctx) {
         int rc = pt_set_scene(c, geoms, nG, mats, nM);
         if (rc != PT_OK) return rc;
@@ -149,10 +149,10 @@ int pt_multi_set_scene(pt_multi *m, const pt_static_geom *geoms, int nG, const p
 
 int pt_multi_set_camera(pt_multi *m, const pt_camera_data *cam)
 {
-    if (!m || !cam) return PT_ERR_INVALID;
+    if (!m || !cam) return pt::fail(PT_ERR_INVALID, "pt_multi_set_camera: invalid argument or state");
     const int H = (int)cam->resolution.y, W = (int)cam->resolution.x;
-    if (H < (int)m->ctx.size() || W < 1) return PT_ERR_INVALID;          // every device needs at least one row
-    if (m->strip > 0 && (long long)m->strip * (long long)m->ctx.size() > (long long)H + m->strip - 1) return PT_ERR_INVALID;
+    if (H < (int)m->ctx.size() || W < 1) return pt::fail(PT_ERR_INVALID, "pt_multi_set_camera: invalid argument or state");          // every device needs at least one row
+    if (m->strip > 0 && (long long)m->strip * (long long)m->ctx.size() > (long long)H + m->strip - 1) return pt::fail(PT_ERR_INVALID, "pt_multi_set_camera: invalid argument or state");
     m->cam = *cam;
     m->have_cam = true;
     m->height = H;
@@ -166,21 +166,21 @@ int pt_multi_set_camera(pt_multi *m, const pt_camera_data *cam)
 
 int pt_multi_band(const pt_multi *m, int k, int *row_begin, int *row_end)
 {
-    if (!m || !m->have_cam || k < 0 || k >= (int)m->ctx.size() || m->strip > 0) return PT_ERR_INVALID;
+    if (!m || !m->have_cam || k < 0 || k >= (int)m->ctx.size() || m->strip > 0) return pt::fail(PT_ERR_INVALID, "pt_multi_band: invalid argument or state");
     band(m->height, (int)m->ctx.size(), k, row_begin, row_end);
     return PT_OK;
 }
 
 int pt_multi_clear_image(pt_multi *m)
 {
-    if (!m) return PT_ERR_INVALID;
+    if (!m) return pt::fail(PT_ERR_INVALID, "pt_multi_clear_image: invalid argument or state");
     for (pt_ctx *c : m->ctx) { int rc = pt_clear_image(c); if (rc != PT_OK) return rc; }
     return PT_OK;
 }
 
 int pt_multi_render(pt_multi *m, int iter_first, int iter_count)
 {
-    if (!m) return PT_ERR_INVALID;
+    if (!m) return pt::fail(PT_ERR_INVALID, "pt_multi_render: invalid argument or state");
     for (pt_ctx *c : m->ctx) {                 // asynchronous on every device's own stream
         int rc = pt_render(c, iter_first, iter_count);
         if (rc != PT_OK) return rc;
@@ -190,7 +190,7 @@ int pt_multi_render(pt_multi *m, int iter_first, int iter_count)
 
 int pt_multi_synchronize(pt_multi *m)
 {
-    if (!m) return PT_ERR_INVALID;
+    if (!m) return pt::fail(PT_ERR_INVALID, "pt_multi_synchronize: invalid argument or state");
     for (pt_ctx *c : m->ctx) { int rc = pt_synchronize(c); if (rc != PT_OK) return rc; }
     return PT_OK;
 }
@@ -198,7 +198,7 @@ int pt_multi_synchronize(pt_multi *m)
 // bands -> one host frame (W*H*3 fp32, row-major): each context copies its band straight into its slice
 int pt_multi_download_image(pt_multi *m, float *host_rgb)
 {
-    if (!m || !host_rgb || !m->have_cam) return PT_ERR_INVALID;
+    if (!m || !host_rgb || !m->have_cam) return pt::fail(PT_ERR_INVALID, "pt_multi_download_image: invalid argument or state");
     const int n = (int)m->ctx.size();
     if (m->strip > 0 && n > 1) return copy_strips(m, host_rgb, nullptr, 0, /*to_frame=*/true);
     for (int k = 0; k < n; ++k) {
@@ -213,7 +213,7 @@ int pt_multi_download_image(pt_multi *m, float *host_rgb)
 // host frame -> bands (resuming an accumulation, ref: src/raytraceKernel.cu:120)
 int pt_multi_upload_image(pt_multi *m, const float *host_rgb)
 {
-    if (!m || !host_rgb || !m->have_cam) return PT_ERR_INVALID;
+    if (!m || !host_rgb || !m->have_cam) return pt::fail(PT_ERR_INVALID, "pt_multi_upload_image: invalid argument or state");
     const int n = (int)m->ctx.size();
     if (m->strip > 0 && n > 1) return copy_strips(m, const_cast<float *>(host_rgb), nullptr, 0, /*to_frame=*/false);
     for (int k = 0; k < n; ++k) {
@@ -229,7 +229,7 @@ int pt_multi_upload_image(pt_multi *m, const float *host_rgb)
 // source device's path to the destination -- a set of concurrent point-to-point transfers, not a ring.
 int pt_multi_gather_to_device(pt_multi *m, void *device_rgb, int dst_device)
 {
-    if (!m || !device_rgb || !m->have_cam) return PT_ERR_INVALID;
+    if (!m || !device_rgb || !m->have_cam) return pt::fail(PT_ERR_INVALID, "pt_multi_gather_to_device: invalid argument or state");
     const int n = (int)m->ctx.size();
     int rc = pt_multi_synchronize(m);
     if (rc != PT_OK) return rc;
@@ -243,18 +243,18 @@ int pt_multi_gather_to_device(pt_multi *m, void *device_rgb, int dst_device)
         rc = pt_image_device_pointer(m->ctx[(size_t)k], &src);
         if (rc != PT_OK) return rc;
         char *dst = (char *)device_rgb + (size_t)r0 * (size_t)m->width * 3 * sizeof(float);
-        if (hipSetDevice(m->device[(size_t)k]) != hipSuccess) return PT_ERR_HIP;
-        if (hipStreamCreateWithFlags(&streams[(size_t)k], hipStreamNonBlocking) != hipSuccess) return PT_ERR_HIP;
+        if (hipSetDevice(m->device[(size_t)k]) != hipSuccess) return pt::fail(PT_ERR_HIP, "pt_multi_gather_to_device: %s", hipGetErrorString(hipGetLastError()));
+        if (hipStreamCreateWithFlags(&streams[(size_t)k], hipStreamNonBlocking) != hipSuccess) return pt::fail(PT_ERR_HIP, "pt_multi_gather_to_device: %s", hipGetErrorString(hipGetLastError()));
         hipError_t e = (m->device[(size_t)k] == dst_device)
                            ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, streams[(size_t)k])
                            : hipMemcpyPeerAsync(dst, dst_device, src, m->device[(size_t)k], bytes, streams[(size_t)k]);
-        if (e != hipSuccess) return PT_ERR_HIP;
+        if (e != hipSuccess) return pt::fail(PT_ERR_HIP, "pt_multi_gather_to_device: %s", hipGetErrorString(e));
     }
     for (int k = 0; k < n; ++k) {
         (void)hipSetDevice(m->device[(size_t)k]);
         hipError_t e = hipStreamSynchronize(streams[(size_t)k]);
         (void)hipStreamDestroy(streams[(size_t)k]);
-        if (e != hipSuccess) return PT_ERR_HIP;
+        if (e != hipSuccess) return pt::fail(PT_ERR_HIP, "pt_multi_gather_to_device: %s", hipGetErrorString(e));
     }
     return PT_OK;
 }
@@ -262,13 +262,13 @@ int pt_multi_gather_to_device(pt_multi *m, void *device_rgb, int dst_device)
 // sendImageToPBO for a single-device handle (the PBO is a device pointer of the GL device)
 int pt_multi_send_image_to_pbo(pt_multi *m, pt_uchar4 *device_pbo)
 {
-    if (!m || m->ctx.size() != 1) return PT_ERR_INVALID;
+    if (!m || m->ctx.size() != 1) return pt::fail(PT_ERR_INVALID, "pt_multi_send_image_to_pbo: invalid argument or state");
     return pt_send_image_to_pbo(m->ctx[0], device_pbo);
 }
 
 int pt_multi_get_stats(pt_multi *m, pt_stats *out)
 {
-    if (!m || !out) return PT_ERR_INVALID;
+    if (!m || !out) return pt::fail(PT_ERR_INVALID, "pt_multi_get_stats: invalid argument or state");
     memset(out, 0, sizeof *out);
     for (pt_ctx *c : m->ctx) {
         pt_stats s;

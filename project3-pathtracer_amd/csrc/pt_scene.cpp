@@ -3,13 +3,15 @@
 // consumes (ref: src/utilities.cpp:74-90, GLM 0.9.5.4 translate/rotate/scale/inverse semantics, fp32).
 //
 // One-time host work; not accelerated.  Compiled with -ffp-contract=off so that matrices equal the
-// reference's bit for bit (checked against real GLM vectors in tests/test_scene_loader.py).
+// reference's bit for bit (checked against real GLM vectors in tests/test_oracle_kat.py (loader dump) and tests/test_abi.py).
 #include "pt_scene.h"
 
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <fstream>
+#include <iterator>
 #include <sstream>
 
 namespace ptamd {
@@ -133,27 +135,40 @@ pt_mat4 toRows(const M4 &m)
     return r;
 }
 
-// utilityCore::safeGetline (ref: src/utilities.cpp:109-140): LF, CRLF and CR line ends
-std::istream &safeGetline(std::istream &is, std::string &t)
+// Line source of the loader: the whole file in memory, cut at LF, CRLF or CR (the line ends the reference's reader
+// accepts, ref: src/utilities.cpp:109-140).  A last line without a line end is still a line; `more()` turns false only
+// once a read found nothing at all, which is when the reference's stream stops being good().
+}  // namespace
+
+bool LineReader::open(const std::string &path)
 {
-    t.clear();
-    std::istream::sentry se(is, true);
-    std::streambuf *sb = is.rdbuf();
-    for (;;) {
-        const int ch = sb->sbumpc();
-        if (ch == '\n') return is;
-        if (ch == '\r') {
-            if (sb->sgetc() == '\n') sb->sbumpc();
-            return is;
-        }
-        if (ch == std::streambuf::traits_type::eof()) {
-            if (t.empty()) is.setstate(std::ios::eofbit);
-            return is;
-        }
-        t += (char)ch;
-    }
+    std::ifstream f(path.c_str(), std::ios::binary);
+    if (!f.is_open()) return false;
+    text_.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    pos_ = 0;
+    exhausted_ = false;
+    return true;
 }
 
+void LineReader::next(std::string &line)
+{
+    const size_t n = text_.size();
+    if (pos_ >= n) {
+        line.clear();
+        exhausted_ = true;
+        return;
+    }
+    const size_t end = text_.find_first_of("\r\n", pos_);
+    if (end == std::string::npos) {
+        line.assign(text_, pos_, n - pos_);
+        pos_ = n;
+        return;
+    }
+    line.assign(text_, pos_, end - pos_);
+    pos_ = end + ((text_[end] == '\r' && end + 1 < n && text_[end + 1] == '\n') ? 2 : 1);
+}
+
+namespace {
 std::vector<std::string> tokenizeString(const std::string &str)
 {
     std::istringstream ss(str);
@@ -195,15 +210,14 @@ pt_vec2 cameraFov(float fovy, pt_vec2 resolution)
 
 scene::scene(const std::string &filename, int rotat_units) : rotat_units_(rotat_units)
 {
-    fp_in.open(filename.c_str());
-    if (!fp_in.is_open()) {
+    if (!fp_in.open(filename)) {
         errors.push_back("cannot open " + filename);
         return;
     }
     ok = true;
-    while (fp_in.good()) {
+    while (fp_in.more()) {
         std::string line;
-        safeGetline(fp_in, line);
+        fp_in.next(line);
         if (line.empty()) continue;
         const std::vector<std::string> tokens = tokenizeString(line);
         if (tokens.empty()) continue;
@@ -211,7 +225,6 @@ scene::scene(const std::string &filename, int rotat_units) : rotat_units_(rotat_
         else if (tokens[0] == "OBJECT" && tokens.size() > 1) loadObject(tokens[1]);
         else if (tokens[0] == "CAMERA") loadCamera();
     }
-    fp_in.close();
 }
 
 int scene::loadMaterial(const std::string &materialid)
@@ -224,7 +237,7 @@ int scene::loadMaterial(const std::string &materialid)
     memset(&m, 0, sizeof m);
     for (int i = 0; i < 10; ++i) {                       // exactly 10 property lines
         std::string line;
-        safeGetline(fp_in, line);
+        fp_in.next(line);
         const std::vector<std::string> t = tokenizeString(line);
         if (t.empty()) continue;
         const std::string &k = t[0];
@@ -249,7 +262,7 @@ int scene::loadCamera()
     float fovy = 0;
     for (int i = 0; i < 4; ++i) {
         std::string line;
-        safeGetline(fp_in, line);
+        fp_in.next(line);
         const std::vector<std::string> t = tokenizeString(line);
         if (t.empty()) continue;
         if (t[0] == "RES") cam.resolution = {(float)(t.size() > 1 ? atoi(t[1].c_str()) : 0), (float)(t.size() > 2 ? atoi(t[2].c_str()) : 0)};
@@ -259,15 +272,15 @@ int scene::loadCamera()
     }
     int frameCount = 0;
     std::string line;
-    safeGetline(fp_in, line);
-    while (!line.empty() && fp_in.good()) {
+    fp_in.next(line);
+    while (!line.empty() && fp_in.more()) {
         std::vector<std::string> t = tokenizeString(line);
         if (t.size() < 2 || t[0] != "frame" || atoi(t[1].c_str()) != frameCount) {
             errors.push_back("Incorrect frame count!");
             return -1;
         }
         for (int i = 0; i < 3; ++i) {
-            safeGetline(fp_in, line);
+            fp_in.next(line);
             t = tokenizeString(line);
             if (t.empty()) continue;
             if (t[0] == "EYE") cam.positions.push_back(field3(t));
@@ -275,7 +288,7 @@ int scene::loadCamera()
             else if (t[0] == "UP") cam.ups.push_back(field3(t));
         }
         frameCount++;
-        safeGetline(fp_in, line);
+        fp_in.next(line);
     }
     cam.frames = frameCount;
     cam.fov = cameraFov(fovy, cam.resolution);
@@ -293,8 +306,8 @@ int scene::loadObject(const std::string &objectid)
     }
     geom g;
     std::string line;
-    safeGetline(fp_in, line);
-    if (!line.empty() && fp_in.good()) {                 // the whole line is compared (ref: src/scene.cpp:49-70)
+    fp_in.next(line);
+    if (!line.empty() && fp_in.more()) {                 // the whole line is compared (ref: src/scene.cpp:49-70)
         if (line == "sphere") g.type = PT_SPHERE;
         else if (line == "cube") g.type = PT_CUBE;
         else {
@@ -309,21 +322,21 @@ int scene::loadObject(const std::string &objectid)
             }
         }
     }
-    safeGetline(fp_in, line);
-    if (!line.empty() && fp_in.good()) {
+    fp_in.next(line);
+    if (!line.empty() && fp_in.more()) {
         const std::vector<std::string> t = tokenizeString(line);
         g.materialid = t.size() > 1 ? atoi(t[1].c_str()) : 0;
     }
     int frameCount = 0;
-    safeGetline(fp_in, line);
-    while (!line.empty() && fp_in.good()) {
+    fp_in.next(line);
+    while (!line.empty() && fp_in.more()) {
         std::vector<std::string> t = tokenizeString(line);
         if (t.size() < 2 || t[0] != "frame" || atoi(t[1].c_str()) != frameCount) {
             errors.push_back("Incorrect frame count!");
             return -1;
         }
         for (int i = 0; i < 3; ++i) {
-            safeGetline(fp_in, line);
+            fp_in.next(line);
             t = tokenizeString(line);
             if (t.empty()) continue;
             if (t[0] == "TRANS") g.translations.push_back(field3(t));
@@ -331,7 +344,7 @@ int scene::loadObject(const std::string &objectid)
             else if (t[0] == "SCALE") g.scales.push_back(field3(t));
         }
         frameCount++;
-        safeGetline(fp_in, line);
+        fp_in.next(line);
     }
     g.frames = frameCount;
     if ((int)g.translations.size() != frameCount || (int)g.rotations.size() != frameCount || (int)g.scales.size() != frameCount) {

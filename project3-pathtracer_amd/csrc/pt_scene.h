@@ -30,6 +30,18 @@ struct camera {
     std::string imageName;
 };
 
+// the scene file as a sequence of lines (LF, CRLF or CR line ends)
+class LineReader {
+public:
+    bool open(const std::string &path);
+    void next(std::string &line);            // the next line without its line end; empty once the text is used up
+    bool more() const { return !exhausted_; }   // false after a read that found nothing left
+private:
+    std::string text_;
+    size_t pos_ = 0;
+    bool exhausted_ = true;
+};
+
 class scene {
 public:
     explicit scene(const std::string &filename, int rotat_units = PT_ROTAT_RADIANS);
@@ -40,7 +52,7 @@ public:
     std::vector<std::string> errors;
 
 private:
-    std::ifstream fp_in;
+    LineReader fp_in;
     int rotat_units_;
     int loadMaterial(const std::string &materialid);
     int loadObject(const std::string &objectid);

@@ -19,11 +19,16 @@
 //                         (pt_multi_*), the bands are gathered into renderCam->image; PBO output then needs 1 device
 //   PT_STRIP_ROWS (8)     with several devices: rows per interleaved strip (device k renders strips k, k+n, ...); 0 = one
 //                         contiguous band per device
-//   PT_SHIM_BATCH (16)    iterations that may be pending inside the shim before they are rendered together
+//   PT_SHIM_BATCH (1)     iterations that may be pending inside the shim before they are rendered together
 //                         (only while nobody can observe them: no PBO, no read-back due); 1 = render every call
-//   PT_READBACK_EVERY (0) also copy the image back every N iterations (0 = only on the last one,
-//                         iterations == renderCam->iterations, which is when src/main.cpp:114-125 reads it);
-//                         1 reproduces the reference's copy on every call
+//   PT_READBACK_EVERY (1) copy renderCam->image back every N iterations; 1 = on every call, as the reference does
+//                         (src/raytraceKernel.cu:154); 0 = only on the last one (iterations == renderCam->iterations,
+//                         which is when src/main.cpp:114-125 reads it)
+// The defaults reproduce the reference call for call: every iteration is rendered and renderCam->image updated
+// before cudaRaytraceCore returns.  A caller that only reads the image at the end (src/main.cpp does) may opt in to
+// deferral with pt_shim_configure(16, 0) -- the headless driver pt_main.cpp does -- and must then call
+// pt_shim_flush() if it stops before iterations == renderCam->iterations: that renders what is still pending and
+// copies the image back, so no accepted iteration is lost.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -32,6 +37,7 @@
 
 #include "../../include/pt_abi.h"
 #include "pt_refstructs.h"
+#include "pt_shim.h"
 
 namespace {
 
@@ -42,10 +48,12 @@ struct ShimState {
     std::vector<pt_material> mats;
     pt_camera_data cam;
     bool have_cam = false;
-    int readback_every = 0;
+    int readback_every = 1;     // PT_READBACK_EVERY / pt_shim_configure
     int last_iteration = 0;     // the last iteration handed to this shim (rendered or pending)
     int pend_first = 0, pend_count = 0;   // iterations accepted but not enqueued yet (rendered in batches)
-    int defer = 16;             // PT_SHIM_BATCH: how many iterations may be pending; 1 = render on every call
+    int defer = 1;              // PT_SHIM_BATCH / pt_shim_configure: how many iterations may be pending; 1 = render on every call
+    bool configured = false;    // pt_shim_configure was called: the environment no longer decides defer / readback_every
+    float *last_image = nullptr;   // renderCam->image of the last call (pt_shim_flush copies the image back there)
 };
 ShimState g;
 
@@ -72,6 +80,22 @@ void flush_pending()
 }
 
 }  // namespace
+
+void pt_shim_configure(int batch, int readback_every)
+{
+    if (g.ctx) flush_pending();
+    g.defer = batch < 1 ? 1 : batch;
+    g.readback_every = readback_every < 0 ? 0 : readback_every;
+    g.configured = true;
+}
+
+void pt_shim_flush(void)
+{
+    if (!g.ctx) return;
+    flush_pending();
+    if (g.last_image) check(pt_multi_download_image(g.ctx, g.last_image), "pt_download_image");
+    check(pt_multi_synchronize(g.ctx), "Kernel failed!");
+}
 
 void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iterations, material *materials,
                       int numberOfMaterials, geom *geoms, int numberOfGeoms)
@@ -100,9 +124,12 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
         o.seed = (unsigned)env_int("PT_SEED", 0);
         check(pt_multi_set_options(g.ctx, &o), "pt_set_options");
         if (g.ndev > 1) check(pt_multi_set_strips(g.ctx, env_int("PT_STRIP_ROWS", 8)), "pt_multi_set_strips");
-        g.readback_every = env_int("PT_READBACK_EVERY", 0);
-        g.defer = env_int("PT_SHIM_BATCH", 16);
+        if (!g.configured) {
+            g.readback_every = env_int("PT_READBACK_EVERY", 1);
+            g.defer = env_int("PT_SHIM_BATCH", 1);
+        }
         if (g.defer < 1) g.defer = 1;
+        if (g.readback_every < 0) g.readback_every = 0;
     }
 
     // package geometry (ref: src/raytraceKernel.cu:123-134).  geom::frames is never initialised by the
@@ -149,9 +176,10 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
         g.have_cam = true;
     }
 
-    // one iteration.  iterations == 1 restarts the running mean (the old image is multiplied by 0); a later
+    // one iteration.  iterations == 1 restarts the running mean (the old image is not read); a later
     // iteration on a context without history first takes the caller's image (ref: src/raytraceKernel.cu:120).
     float *host_image = reinterpret_cast<float *>(renderCam->image);
+    g.last_image = host_image;
     const bool last = (unsigned)iterations >= renderCam->iterations;
     const bool readback = host_image && (last || (g.readback_every > 0 && iterations % g.readback_every == 0));
     if (iterations != g.last_iteration + 1) {

@@ -1,0 +1,13 @@
+// pt_shim.h -- optional controls of the reference-side binding (pt_shim.cpp).  The renderer entry point itself is
+// declared by the reference's own header (ref: src/raytraceKernel.h:17); a caller that never includes this file gets
+// the reference's behaviour: every cudaRaytraceCore call renders its iteration and updates renderCam->image.
+#pragma once
+
+// batch: iterations the shim may hold back and render together while nobody can observe them (no PBO, no image
+//        read-back due); 1 = render on every call.
+// readback_every: copy renderCam->image back every N iterations; 0 = only when iterations == renderCam->iterations.
+// Overrides PT_SHIM_BATCH / PT_READBACK_EVERY.
+void pt_shim_configure(int batch, int readback_every);
+// Render whatever is still pending, copy the image into the renderCam->image of the last call, synchronize.
+// Needed only after opting in to deferral, when the caller stops before the scene's last iteration.
+void pt_shim_flush(void);

@@ -62,6 +62,22 @@ def test_library_does_not_link_the_oracle(pkg):
                 assert "oracle/" not in src and "pt_oracle" not in src and "oracle_lib" not in src, f
 
 
+def test_shim_exports_the_symbol_main_cpp_links(pkg):
+    """The reference's main.cpp calls cudaRaytraceCore through its C++-mangled name (ref: src/raytraceKernel.h:17,
+    src/main.cpp:110): the binding must define exactly that symbol -- Itanium mangling of
+    void cudaRaytraceCore(uchar4*, camera*, int, int, material*, int, geom*, int) -- plus the two optional controls."""
+    assert os.path.exists(pkg.HEADLESS_PATH)
+    syms = subprocess.run(["nm", "--defined-only", pkg.HEADLESS_PATH], capture_output=True, text=True).stdout
+    defined = {ln.split()[-1] for ln in syms.splitlines() if ln.split()}
+    assert "_Z16cudaRaytraceCoreP6uchar4P6cameraiiP8materialiP4geomi" in defined
+    assert "_Z17pt_shim_configureii" in defined and "_Z13pt_shim_flushv" in defined
+    # and what it leaves undefined is the C-ABI only (no kernels, no HIP runtime in the binding itself)
+    und = subprocess.run(["nm", "--undefined-only", pkg.HEADLESS_PATH], capture_output=True, text=True).stdout
+    wanted = {ln.split()[-1] for ln in und.splitlines() if ln.split() and ln.split()[-1].startswith("pt_")}
+    assert wanted and wanted <= set(declared_functions()), wanted - set(declared_functions())
+    assert not re.search(r"\bhip[A-Z]", und)
+
+
 def test_pod_layouts_match_reference(pkg, golden):
     lay = golden["reference_vectors"]["layouts"]
     for cls, key in ((pkg.StaticGeom, "staticGeom"), (pkg.Material, "material"), (pkg.CameraData, "cameraData")):

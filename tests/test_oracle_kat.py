@@ -272,3 +272,22 @@ def test_render_checksums():
     for case in gen.CASES:
         got = gen.run(case)
         assert got["sha256"] == want[case[0]]["sha256"] and got["live_in"] == want[case[0]]["live_in"], case[0]
+
+
+def test_render_checksums_large():
+    """The benchmark-shape fixture (tests/golden/render_checksums_large.json) names every case of its generator and the
+    cheapest case re-hashes to the committed value; PT_TEST_LARGE_GOLDEN=1 re-runs all of them (minutes of CPU time)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_render_golden_large", os.path.join(root, "oracle", "make_render_golden_large.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    want = json.load(open(os.path.join(root, "tests", "golden", "render_checksums_large.json")))
+    assert sorted(want) == sorted(c[0] for c in gen.CASES)
+    everything = os.environ.get("PT_TEST_LARGE_GOLDEN", "0") == "1"
+    for case in gen.CASES:
+        if not everything and case[0] != "config5_cloud_480x270_depth32_rr":
+            continue
+        got = gen.run(case)
+        assert got["sha256"] == want[case[0]]["sha256"] and got["live_in"] == want[case[0]]["live_in"], case[0]
+        assert got["row_sha256"] == want[case[0]]["row_sha256"]
