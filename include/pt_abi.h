@@ -84,11 +84,13 @@ typedef struct pt_options {
     int compaction;       /* live-ray compaction after every bounce: 1 = per-wave reservation in 32 pool segments, no
                              barrier (default); 2 = workgroup LDS scan + one counter; 0 = off, rays keep their slot */
     int workgroup;        /* threads per workgroup: 64, 128, 256, 512 or 1024 (default 0 = library choice) */
-    int geom_path;        /* how primitives reach the lanes: 0 = library choice (default: 5 up to 40 primitives, else 6),
+    int geom_path;        /* how primitives reach the lanes: 0 = library choice (default: 5 up to 40 primitives, else 7),
                              1 = scalar (SGPR) loads, 2 = staged in LDS, 3 = scalar candidate test + wave-private LDS hit
                              queue, 4 = per-lane walk of an LDS-resident bounding-box hierarchy (large scenes), 5 = per-lane
                              box pre-test + wave-private queue of (ray, primitive) pairs, exact test on full batches,
-                             6 = hierarchy walk with box tests only that queues the leaves it reaches as pairs (large scenes) */
+                             6 = hierarchy walk with box tests only that queues the leaves it reaches as pairs (large scenes),
+                             7 = 4-wide hierarchy walked in full 64-entry batches of (ray, node) entries from a wave-private
+                             LDS stack, leaves queued as pairs (large scenes) */
     int row_begin;        /* tile rendered by this context: rows [row_begin, row_end) of the frame; */
     int row_end;          /*   0,0 = the whole frame.  RNG streams are keyed on the global pixel index. */
     int use_graph;        /* 1 = replay one captured hipGraph per launch sequence (default), 0 = eager launches */

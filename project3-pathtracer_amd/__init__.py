@@ -18,7 +18,7 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libptamd.so")
+LIB_PATH = os.environ.get("PT_LIBPTAMD") or os.path.join(LIB_DIR, "libptamd.so")   # PT_LIBPTAMD: a diagnostic build (csrc/Makefile OUT=...)
 HEADLESS_PATH = os.path.join(LIB_DIR, "pt_headless")
 ROOT = os.path.dirname(PKG_DIR)
 HEADER_PATH = os.path.join(ROOT, "include", "pt_abi.h")
@@ -83,7 +83,7 @@ _lib = None
 
 def build(verbose=False):
     """Compile libptamd.so and pt_headless for gfx950 with hipcc (cross-compiles without a GPU)."""
-    res = subprocess.run(["make", "-C", CSRC_DIR, "-j4"], capture_output=True, text=True)
+    res = subprocess.run(["make", "-C", CSRC_DIR, "-j8"], capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout)
         print(res.stderr)

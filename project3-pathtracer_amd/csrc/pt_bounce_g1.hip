@@ -1,0 +1,7 @@
+// pt_bounce_g1.hip -- k_bounce instances of geometry path 1 (pt_bounce.h GEOM_*), a translation unit of its own so that
+// the paths compile in parallel.
+#include "pt_bounce.h"
+
+namespace pt {
+const void *bounce_kernel_g1(int workgroup, bool first, int compact, int nee) { return bounce_kernel_for<1>(workgroup, first, compact, nee); }
+}  // namespace pt

@@ -77,6 +77,8 @@ struct pt_ctx {
     float *d_box_world = nullptr;
     int *d_lights = nullptr;    // direct lighting: indices of the emissive primitives
     ptd::BvhNode *d_bvh = nullptr;
+    float *d_bvh4 = nullptr;    // 4-wide hierarchy (geom_path 7)
+    float *d_pgroups = nullptr; // every primitive's world box, four per 4-wide record (pair queue pre-test)
     float *d_image_own = nullptr;
     float *d_image_bound = nullptr;
     size_t image_bytes = 0, image_cap = 0;
@@ -205,6 +207,57 @@ void build_bvh(const std::vector<Aabb> &boxes, std::vector<int> &idx, size_t lo,
     }
     for (int a = 0; a < 3; ++a) { nodes[me].lo[a] = u.lo[a]; nodes[me].hi[a] = u.hi[a]; }
     nodes[me].skip = (uint32_t)nodes.size();          // first node after this subtree
+}
+
+
+// 4-wide hierarchy for geom_path 7, collapsed from the binary one (depth-first, skip links: the left child of internal
+// node i is i + 1, the right child is nodes[i + 1].skip): a wide node takes the two children of a binary node and keeps
+// replacing the child with the largest box by that child's own two children until it has four (or only leaves are left).
+// Record = ptd::W4_FLOATS floats: per axis the four children's lo planes then their hi planes (x: [0..8), y: [8..16),
+// z: [16..24)), then four child words (bit 31 leaf, bit 30 primitive type, bits 6..29 node / primitive index; the low
+// six bits stay free for the owner lane of a traversal entry).  An empty child has lo = +3e38, hi = -3e38: no ray passes.
+int build_wide4(const std::vector<ptd::BvhNode> &bin, const std::vector<pt_static_geom> &geoms, int b, int depth,
+                std::vector<float> &out, int &maxdepth)
+{
+    auto is_leaf = [&](int i) { return bin[(size_t)i].prim >= 0; };
+    auto area = [&](int i) {
+        const ptd::BvhNode &n = bin[(size_t)i];
+        const double dx = (double)n.hi[0] - n.lo[0], dy = (double)n.hi[1] - n.lo[1], dz = (double)n.hi[2] - n.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    std::vector<int> kids;
+    if (is_leaf(b)) kids.push_back(b);                    // a one-primitive hierarchy: the root is that leaf
+    else { kids.push_back(b + 1); kids.push_back((int)bin[(size_t)b + 1].skip); }
+    while (kids.size() < 4) {
+        int best = -1;
+        for (size_t k = 0; k < kids.size(); ++k)
+            if (!is_leaf(kids[k]) && (best < 0 || area(kids[k]) > area(kids[(size_t)best]))) best = (int)k;
+        if (best < 0) break;
+        const int n = kids[(size_t)best];
+        kids[(size_t)best] = n + 1;
+        kids.push_back((int)bin[(size_t)n + 1].skip);
+    }
+    const int me = (int)(out.size() / ptd::W4_FLOATS);
+    out.resize(out.size() + ptd::W4_FLOATS, 0.0f);
+    if (depth > maxdepth) maxdepth = depth;
+    for (int c = 0; c < 4; ++c) {
+        uint32_t word = 0u;
+        float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+        if (c < (int)kids.size()) {
+            const ptd::BvhNode &n = bin[(size_t)kids[(size_t)c]];
+            for (int a = 0; a < 3; ++a) { lo[a] = n.lo[a]; hi[a] = n.hi[a]; }
+            if (n.prim >= 0) {
+                const uint32_t prim = (uint32_t)n.prim & 0x3FFFFFFFu;
+                word = 0x80000000u | (geoms[prim].type == PT_CUBE ? 0x40000000u : 0u) | (prim << 6);
+            } else {
+                word = (uint32_t)build_wide4(bin, geoms, kids[(size_t)c], depth + 1, out, maxdepth) << 6;
+            }
+        }
+        float *rec = out.data() + (size_t)me * ptd::W4_FLOATS;       // (re-fetched: the recursion grows the vector)
+        for (int a = 0; a < 3; ++a) { rec[8 * a + c] = lo[a]; rec[8 * a + 4 + c] = hi[a]; }
+        memcpy(&rec[24 + c], &word, 4);
+    }
+    return me;
 }
 
 // (re)build everything that depends on scene, camera or options
@@ -441,6 +494,29 @@ int configure(pt_ctx *c)
                 be[8 * i + 4 + (size_t)a] = (float)(hi + pad);
             }
         }
+        {
+            // the same world boxes four primitives to a record (ptd::W4_FLOATS floats, the batched walk's node format):
+            // floats [8a, 8a+4) lo planes on axis a, [8a+4, 8a+8) hi planes, dwords 24..27 child words
+            const size_t ng = (c->geoms.size() + 3) / 4;
+            std::vector<float> grp((ng ? ng : 1) * ptd::W4_FLOATS, 0.0f);
+            for (size_t r = 0; r < ng; ++r)
+                for (int cc = 0; cc < 4; ++cc) {
+                    const size_t i = r * 4 + (size_t)cc;
+                    float *rec = grp.data() + r * ptd::W4_FLOATS;
+                    uint32_t word = 0u;
+                    for (int a = 0; a < 3; ++a) { rec[8 * a + cc] = 3e38f; rec[8 * a + 4 + cc] = -3e38f; }
+                    if (i < c->geoms.size() && c->geoms[i].type != PT_MESH) {
+                        for (int a = 0; a < 3; ++a) { rec[8 * a + cc] = bw[8 * i + (size_t)a]; rec[8 * a + 4 + cc] = bw[8 * i + 4 + (size_t)a]; }
+                        word = 0x80000000u | (c->geoms[i].type == PT_CUBE ? 0x40000000u : 0u) | ((uint32_t)i << 6);
+                    }
+                    memcpy(&rec[24 + cc], &word, 4);
+                }
+            if (c->d_pgroups) { (void)hipFree(c->d_pgroups); c->d_pgroups = nullptr; }
+            HIP_TRY(hipMalloc((void **)&c->d_pgroups, grp.size() * sizeof(float)));
+            HIP_TRY(hipMemcpy(c->d_pgroups, grp.data(), grp.size() * sizeof(float), hipMemcpyHostToDevice));
+            k.pgroups = c->d_pgroups;
+            k.npgroups = (int)ng;
+        }
         if (c->d_box_eye) { (void)hipFree(c->d_box_eye); c->d_box_eye = nullptr; }
         HIP_TRY(hipMalloc((void **)&c->d_box_eye, be.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(c->d_box_eye, be.data(), be.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -503,6 +579,18 @@ int configure(pt_ctx *c)
         for (auto &nd : nodes)
             if (nd.prim >= 0) nd.prim |= (c->geoms[(size_t)nd.prim].type == PT_CUBE ? 1 : 0) << 30;
         k.nnodes = (int)nodes.size();
+        {
+            std::vector<float> wide;
+            int wdepth = 0;
+            if (!nodes.empty()) build_wide4(nodes, c->geoms, 0, 1, wide, wdepth);
+            k.nnodes4 = (int)(wide.size() / ptd::W4_FLOATS);
+            k.wdepth = wdepth;
+            if (c->d_bvh4) { (void)hipFree(c->d_bvh4); c->d_bvh4 = nullptr; }
+            if (wide.empty()) wide.resize(ptd::W4_FLOATS, 0.0f);
+            HIP_TRY(hipMalloc((void **)&c->d_bvh4, wide.size() * sizeof(float)));
+            HIP_TRY(hipMemcpy(c->d_bvh4, wide.data(), wide.size() * sizeof(float), hipMemcpyHostToDevice));
+            k.bvh4 = c->d_bvh4;
+        }
         if (c->d_bvh) { (void)hipFree(c->d_bvh); c->d_bvh = nullptr; }
         if (nodes.empty()) nodes.push_back(ptd::BvhNode());
         HIP_TRY(hipMalloc((void **)&c->d_bvh, nodes.size() * sizeof(ptd::BvhNode)));
@@ -530,14 +618,34 @@ int configure(pt_ctx *c)
     // launch shape: persistent workgroups, as many as are resident at once
     pt::LaunchCfg &cfg = c->cfg;
     cfg.workgroup = o.workgroup ? o.workgroup : 256;
-    // library choice: the pair queue's pre-test is linear in the primitive count, the hierarchy walk logarithmic but
-    // divergent: measured crossover near 40 primitives (profiles/r01/crossover_pair_vs_walk.txt)
-    cfg.geom = o.geom_path == 0 ? (k.nG <= 40 ? 4 : 5) : o.geom_path - 1;
+    // library choice: the pair queue's pre-test is linear in the primitive count, the hierarchy walks logarithmic:
+    // measured crossover near 40 primitives (profiles/r01/crossover_pair_vs_walk.txt); above it the batched 4-wide walk
+    cfg.geom = o.geom_path == 0 ? (k.nG <= 40 ? 4 : 6) : o.geom_path - 1;
     cfg.compact = o.compaction;
     cfg.nee = k.nlights > 0 ? 1 : 0;             // no lights: nothing to sample, the plain kernels are exact
     k.cull = (k.nG > 32 && !getenv("PT_NO_CULL")) ? 1 : 0;
     k.nshard = (cfg.compact == 1) ? pt::NSHARD : 1;
     size_t lds = pt::bounce_lds_bytes(k, cfg);
+    if (cfg.geom == 6 && o.workgroup == 0) {
+        // the batched walk keeps 7.5 KiB of LDS per wave beside the node copy: take the workgroup size that puts most
+        // waves on a CU (a larger workgroup shares one node copy among more waves)
+        int best_wg = cfg.workgroup;
+        long long best_waves = 0;
+        for (int wg : {256, 512}) {
+            pt::LaunchCfg t = cfg;
+            t.workgroup = wg;
+            const long long fit = (160LL * 1024) / ((long long)pt::bounce_lds_bytes(k, t) + 1300);
+            const long long waves = std::min<long long>(fit * (wg / 64), 24);
+            if (waves > best_waves) { best_waves = waves; best_wg = wg; }
+        }
+        cfg.workgroup = best_wg;
+        lds = pt::bounce_lds_bytes(k, cfg);
+    }
+    if (cfg.geom == 6 && lds > 96 * 1024 && o.geom_path == 0) {
+        cfg.geom = 5;                              // node copy too large for two workgroups per CU: the per-lane walk
+        cfg.workgroup = o.workgroup ? o.workgroup : 256;
+        lds = pt::bounce_lds_bytes(k, cfg);
+    }
     if (lds > 160 * 1024 && o.geom_path == 0) {
         // the hierarchy (32 B per node, 2 nodes per primitive) no longer fits the CU's LDS: fall back to the scalar
         // loop with the per-wave bounding-sphere cull, which needs none
@@ -743,6 +851,8 @@ void pt_destroy(pt_ctx *c)
     if (c->d_box_world) (void)hipFree(c->d_box_world);
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_bvh) (void)hipFree(c->d_bvh);
+    if (c->d_bvh4) (void)hipFree(c->d_bvh4);
+    if (c->d_pgroups) (void)hipFree(c->d_pgroups);
     if (c->d_image_own) (void)hipFree(c->d_image_own);
     if (c->d_pool) (void)hipFree(c->d_pool);
     if (c->d_lbuf) (void)hipFree(c->d_lbuf);
@@ -758,7 +868,7 @@ int pt_set_options(pt_ctx *c, const pt_options *o)
     const int wg = o->workgroup;
     if (!(wg == 0 || wg == 64 || wg == 128 || wg == 256 || wg == 512 || wg == 1024))
         return fail(PT_ERR_INVALID, "workgroup %d not one of 0,64,128,256,512,1024", wg);
-    if (o->geom_path < 0 || o->geom_path > 6) return fail(PT_ERR_INVALID, "geom_path %d not in 0..6", o->geom_path);
+    if (o->geom_path < 0 || o->geom_path > 7) return fail(PT_ERR_INVALID, "geom_path %d not in 0..7", o->geom_path);
     if (o->row_begin < 0 || o->row_end < o->row_begin) return fail(PT_ERR_INVALID, "tile rows [%d,%d)", o->row_begin, o->row_end);
     if (o->strip_rows < 0 || (o->strip_rows > 0 && (o->strip_world < 1 || o->strip_rank < 0 || o->strip_rank >= o->strip_world)))
         return fail(PT_ERR_INVALID, "strips: rows %d, rank %d of %d", o->strip_rows, o->strip_rank, o->strip_world);
@@ -1060,6 +1170,10 @@ int pt_get_stats(pt_ctx *c, pt_stats *out)
         fprintf(stderr, "[ptamd] hierarchy walk: %.1f nodes, %.2f leaves per ray; per wave (longest lane): %.1f nodes, %.2f leaves, %.2f rounds\n",
                 (double)h.dbg[0] / (double)h.dbg[2], (double)h.dbg[1] / (double)h.dbg[2], (double)h.dbg[3] / (double)h.dbg[6],
                 (double)h.dbg[4] / (double)h.dbg[6], (double)h.dbg[5] / (double)h.dbg[6]);
+    if (getenv("PT_DEBUG_W4") && h.dbg[2] && h.dbg[3] && h.dbg[6])
+        fprintf(stderr, "[ptamd] batched walk: %.2f entries per ray, %.1f steps per wave round, %.1f entries per step, %.1f pairs per round\n",
+                (double)h.dbg[0] / (double)h.dbg[2], (double)h.dbg[3] / (double)h.dbg[6], (double)h.dbg[0] / (double)h.dbg[3],
+                (double)h.dbg[7] / (double)h.dbg[6]);
     if (getenv("PT_DEBUG_CLOCK") && h.dbg[7]) fprintf(stderr, "[ptamd] pairs per wave round: %.1f\n", (double)h.dbg[7] / (double)h.dbg[6]);
     return PT_OK;
 }

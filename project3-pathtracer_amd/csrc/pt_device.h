@@ -140,6 +140,13 @@ struct BvhNode {
 };
 static_assert(sizeof(BvhNode) == 32, "BvhNode must be 32 B");
 
+// 4-wide hierarchy node (geom_path 7): 28 dwords = 112 B.  floats [8a, 8a+4) = lo planes of the four children on axis a,
+// [8a+4, 8a+8) = their hi planes; dwords 24..27 = child words.  A lane reads the NEAR planes of all four children with one
+// ds_read_b128 at (8a + (direction negative ? 4 : 0)) and the FAR planes at the other half: no min/max per slab.  The
+// 28-dword stride walks the 64 LDS banks in steps of 4 with period 16, so the 16 lanes of a ds_read_b128 group reading
+// the same field of different nodes rarely meet on a bank.
+static constexpr int W4_FLOATS = 28;
+
 // Material planes (SoA): plane k of material id at mats[k * nM + id]
 enum { M_CR = 0, M_CG, M_CB, M_SR, M_SG, M_SB, M_REFL, M_REFR, M_IOR, M_EMIT, M_AR, M_AG, M_AB, M_PLANES };
 

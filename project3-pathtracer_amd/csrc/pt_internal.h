@@ -62,6 +62,11 @@ struct KParams {
     const ptd::Prim *prims;
     const ptd::BvhNode *bvh;   // culling hierarchy over the primitives (GEOM 3), depth-first with skip links
     int nnodes;
+    const float *bvh4;     // the same hierarchy collapsed to 4-wide nodes (GEOM_WALK4), ptd::W4_FLOATS floats per node
+    int nnodes4;
+    int wdepth;            // its depth in nodes (bounds the traversal stack)
+    const float *pgroups;  // all primitives' padded world boxes in 4-wide records, four primitives each in list order (pair queue pre-test)
+    int npgroups;
     int nbig;              // primitives too large to cull (walls...): tested by every ray before the walk
     int big[16];           // their indices
     const float *face_n;   // per primitive: 8 float4, entry `face code` = world normal of that box face (boxNormal's result)
@@ -93,7 +98,8 @@ struct KParams {
 struct LaunchCfg {
     int workgroup;   // 64..1024
     int grid;        // workgroups per bounce launch
-    int geom;        // 0 scalar direct, 1 LDS direct, 2 hit queue, 3 per-lane hierarchy walk, 4 pair queue (pt_kernels.hip)
+    int geom;        // 0 scalar direct, 1 LDS direct, 2 hit queue, 3 per-lane hierarchy walk, 4 pair queue, 5 walk + pairs,
+                     // 6 batched 4-wide walk + pairs (pt_kernels.hip)
     int compact;     // 0 off, 1 per-wave sharded reservation, 2 workgroup scan + single counter
     int nee;         // 1 = explicit light sampling at diffuse vertices (compact must be 1)
 };

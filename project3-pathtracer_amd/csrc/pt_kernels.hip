@@ -9,7 +9,7 @@
 //                          hipGraph can be replayed per iteration
 //
 // Execution model (wave64): one lane = one live ray, up to 16 iterations in flight per launch.  The nearest-hit
-// search comes in six interchangeable forms (GEOM_*, below); the default ones first run a cheap per-lane box
+// search comes in seven interchangeable forms (GEOM_* in pt_bounce.h, where k_bounce lives); the default ones first run a cheap per-lane box
 // pre-test and then do the exact intersection work on full 64-wide batches of (ray, primitive) pairs drawn
 // from a wave-private LDS queue.  Rays live in SoA pools (pt_internal.h RayPool); survivors of a bounce are
 // written densely into the other pool: wave ballot + v_mbcnt prefix and ONE atomic per wave on one of 32
@@ -19,1178 +19,11 @@
 // Compile with -ffp-contract=off (see pt_device.h).
 #include <stdlib.h>
 
-#include "pt_internal.h"
+#include <algorithm>
+
+#include "pt_bounce.h"
 
 namespace pt {
-using namespace ptd;
-
-static constexpr uint32_t DEAD = 0xFFFFFFFFu;
-static constexpr bool DEBUG_CULL = false;
-static constexpr bool DEBUG_PAIR = false;
-static constexpr bool DEBUG_PHASE = false;       // per-wave shader-clock stamps between the phases of a chunk -> IterState::dbg
-static constexpr bool DEBUG_BVH = false;        // count node / leaf visits of the hierarchy walk into IterState::dbg
-static constexpr int MAXSLOT = 16;                // iterations in flight per launch sequence (pt_internal.h PT_MAX_BATCH)
-static constexpr uint32_t SLOT_SHIFT = 27;        // pixel word = tile-local pixel | slot << 27 | NEE mark << 31
-static constexpr uint32_t PIX_MASK = (1u << SLOT_SHIFT) - 1u;
-
-typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
-
-// Wave-uniform primitive fetch through the constant address space: hipcc turns this into s_load_dwordx16 x2
-// and keeps the record in SGPRs.
-__device__ __forceinline__ Prim load_prim_scalar(const Prim *prims, int g)
-{
-    Prim r;
-    const_u32_ptr q = (const_u32_ptr)(uintptr_t)(prims + g);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(&r);
-#pragma unroll
-    for (int k = 0; k < 32; ++k) dst[k] = q[k];
-    return r;
-}
-
-struct Hit {
-    f3 p, n;
-    uint32_t material;
-    uint32_t prim;      // index of the primitive hit (used by shadow rays)
-    float t;            // world-space distance to the hit
-    bool any;
-};
-
-// GEOM selects how the primitive list reaches the lanes:
-//   0  direct, scalar: records through s_load into SGPRs; hit work inside the wave-uniform primitive loop
-//   1  direct, LDS:    records staged in LDS, broadcast reads; same loop
-//   2  hit queue:      the uniform loop only finds candidates (object-space t); every (ray, primitive, t)
-//                      candidate is appended to a wave-private LDS queue and the expensive hit work (world
-//                      point, distance) runs on full 64-candidate batches with every lane busy, whichever
-//                      ray or primitive a candidate belongs to.  Results flow back to the owning lane through
-//                      a 64-bit LDS atomic min on (distance bits, primitive index).
-//   3  hierarchy walk: for large primitive lists.  Every lane walks a bounding-box hierarchy of the primitives
-//                      (LDS-resident, depth-first with skip links, no stack) and runs the exact test only on the
-//                      leaves its ray can reach; per-lane primitive records are gathered from the LDS copy.  The
-//                      boxes are padded and only ever cull, so the nearest hit (ties -> lowest index) is unchanged.
-//   4  pair queue:     the uniform loop only runs a cheap per-lane test of the ray against the primitive's padded world
-//                      box and queues the (ray, primitive) pairs that pass -- spheres and boxes apart; the candidate test
-//                      itself AND the hit work then run on full 64-pair batches, each lane on its own pair (ray from
-//                      the owner's LDS slot, primitive record gathered from the LDS copy), results through the same
-//                      64-bit LDS atomic min.  The box test only ever drops pairs the exact test would miss.
-//   5  walk + pairs:   large primitive lists.  The scene-spanning primitives go through the pair queue first, which gives
-//                      every ray an upper bound on its hit distance; each lane then walks the hierarchy with box tests
-//                      only, pruned by that bound, and queues the leaves it reaches as (ray, primitive) pairs; the exact
-//                      tests run on full batches as in 4.
-enum { GEOM_SCALAR = 0, GEOM_LDS = 1, GEOM_QUEUE = 2, GEOM_BVH = 3, GEOM_PAIR = 4, GEOM_WALK_PAIR = 5 };
-
-// Conservative cull for large primitive lists: true when NO lane of the wave can hit the primitive, judged by a
-// padded world-space bounding sphere (centre = transform*(0,0,0,1), radius^2 in the record).  It only ever skips
-// primitives whose exact test would miss for every lane, so results are unchanged; the wave-uniform ballot makes
-// the skip a scalar branch.
-__device__ __forceinline__ bool waveMissesBound(const Prim &P, f3 o, f3 d)
-{
-    const f3 oc = o - mk(P.cx, P.cy, P.cz);
-    const float b = dot(oc, d);
-    const float oc2 = dot(oc, oc);
-    const float perp2 = oc2 - b * b;                       // squared distance of the centre from the ray's line
-    // origin outside and leaving, or the line passes outside the sphere; oc2*1e-5 covers the fp32 cancellation in
-    // perp2 and |d| = 1 +- 1e-6 (the radius itself is already padded by 2 % + 1e-3 on the host)
-    const bool reject = (oc2 > P.bound_r2 && b > 0.0f) || (perp2 > P.bound_r2 + oc2 * 1e-5f);
-    return __ballot(!reject) == 0ull;
-}
-
-// wave-uniform fetch of inverseTransform*(eye,1) of primitive g (camera rays only)
-__device__ __forceinline__ f3 load_ro_eye(const float *ro_eye, int g)
-{
-    const_u32_ptr q = (const_u32_ptr)(uintptr_t)(ro_eye + 4 * g);
-    return mk(__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]));
-}
-
-// Camera rays only (they share the eye as origin): true when no ray of the wave can reach primitive g, judged by
-// its padded world box relative to the eye (host-side, KParams::box_eye).  It only ever skips primitives the exact
-// test would miss for every lane.  inv = approximate, finite reciprocal of the ray direction.
-__device__ __forceinline__ bool waveMissesBoxFromEye(const float *box_eye, int g, f3 inv, bool valid)
-{
-    const_u32_ptr q = (const_u32_ptr)(uintptr_t)(box_eye + 8 * g);
-    const float x0 = __uint_as_float(q[0]) * inv.x, x1 = __uint_as_float(q[4]) * inv.x;
-    const float y0 = __uint_as_float(q[1]) * inv.y, y1 = __uint_as_float(q[5]) * inv.y;
-    const float z0 = __uint_as_float(q[2]) * inv.z, z1 = __uint_as_float(q[6]) * inv.z;
-    const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
-    const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-    return (__builtin_amdgcn_fcmpf(tn, tf, FCMP_OLE) & __ballot(valid)) == 0ull;
-}
-__device__ __forceinline__ f3 approxInverse(f3 d)
-{
-    return mk(__builtin_amdgcn_rcpf(fabsf(d.x) > 1e-20f ? d.x : (d.x < 0 ? -1e-20f : 1e-20f)),
-              __builtin_amdgcn_rcpf(fabsf(d.y) > 1e-20f ? d.y : (d.y < 0 ? -1e-20f : 1e-20f)),
-              __builtin_amdgcn_rcpf(fabsf(d.z) > 1e-20f ? d.z : (d.z < 0 ? -1e-20f : 1e-20f)));
-}
-
-template <int GEOM, bool FIRST>
-__device__ __forceinline__ Hit nearestHitDirect(const KParams &p, const Prim *s_prims, f3 o, f3 d)
-{
-    Hit h;
-    h.any = false;
-    h.material = 0;
-    h.prim = 0;
-    h.p = mk(0, 0, 0);
-    h.n = mk(0, 0, 0);
-    float best_t = 0.0f;
-    for (int g = 0; g < p.nG; ++g) {
-        f3 ip, in;
-        float t;
-        uint32_t mat;
-        if (GEOM == GEOM_LDS) {
-            const Prim &P = s_prims[g];
-            if (p.cull && waveMissesBound(P, o, d)) continue;
-            t = intersectPrim<FIRST>(P, o, d, FIRST ? load_ro_eye(p.ro_eye, g) : o, ip, in);
-            mat = P.material;
-        } else {
-            const Prim P = load_prim_scalar(p.prims, g);
-            if (p.cull) {
-                const bool skip = waveMissesBound(P, o, d);
-                if (DEBUG_CULL && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicAdd(&p.st->clk[skip ? 3 : 2], 1ull);
-                if (skip) continue;
-            }
-            t = intersectPrim<FIRST>(P, o, d, FIRST ? load_ro_eye(p.ro_eye, g) : o, ip, in);
-            mat = P.material;
-        }
-        if (t > 0 && (!h.any || t < best_t)) {      // smallest t > 0, ties keep the lowest index
-            h.any = true;
-            best_t = t;
-            h.p = ip;
-            h.n = in;
-            h.material = mat;
-            h.prim = (uint32_t)g;
-        }
-    }
-    h.t = best_t;
-    return h;
-}
-
-template <bool FIRST>
-__device__ __forceinline__ Hit nearestHitBvh(const KParams &p, const Prim *s_prims, const float4 *s_nodes, f3 o, f3 d)
-{
-    Hit h;
-    h.any = false;
-    h.material = 0;
-    h.p = mk(0, 0, 0);
-    h.n = mk(0, 0, 0);
-    float best_t = 0.0f;
-    uint32_t best_g = 0xFFFFFFFFu;
-    // reciprocal direction for the box slabs: culling only, so an approximate, finite value is enough
-    const float ix = __builtin_amdgcn_rcpf(fabsf(d.x) > 1e-20f ? d.x : (d.x < 0 ? -1e-20f : 1e-20f));
-    const float iy = __builtin_amdgcn_rcpf(fabsf(d.y) > 1e-20f ? d.y : (d.y < 0 ? -1e-20f : 1e-20f));
-    const float iz = __builtin_amdgcn_rcpf(fabsf(d.z) > 1e-20f ? d.z : (d.z < 0 ? -1e-20f : 1e-20f));
-    // primitives that span most of the scene (walls, big lights) would bloat every box above them: they are kept
-    // out of the hierarchy and tested by every ray, wave-uniformly through the scalar unit
-    // the normal is only needed for the final winner: candidates keep (distance, primitive, point, box face)
-    uint32_t best_face = 0u;
-    for (int k = 0; k < p.nbig; ++k) {
-        const int g = p.big[k];
-        const Prim P = load_prim_scalar(p.prims, g);
-        f3 ro = FIRST ? load_ro_eye(p.ro_eye, g) : o, rd;
-        float tc;
-        uint32_t face;
-        if (!candidateT<FIRST>(P.type, P.inv, o, d, ro, rd, tc, face)) continue;
-        f3 ip;
-        const float t = hitPoint(P.fwd, o, ro, rd, tc, ip);
-        if (t > 0 && (!h.any || t < best_t || (t == best_t && (uint32_t)g < best_g))) {
-            h.any = true;
-            best_t = t;
-            best_g = (uint32_t)g;
-            best_face = face;
-            h.p = ip;
-        }
-    }
-    uint32_t i = 0;
-    const uint32_t nn = (uint32_t)p.nnodes;
-    uint32_t dbg_nodes = 0, dbg_leaves = 0, dbg_outer = 0, dbg_inner_wave = 0;
-    for (;;) {
-        // walk to the next leaf this ray can reach (box tests only), so that the lanes of the wave then run the
-        // long exact test together instead of one lane at a time
-        int prim = -1;
-        if (DEBUG_BVH) dbg_outer++;
-        while (i < nn) {
-            if (DEBUG_BVH) dbg_nodes++;
-            const float4 a = s_nodes[2 * i], b = s_nodes[2 * i + 1];
-            const float x0 = (a.x - o.x) * ix, x1 = (b.x - o.x) * ix;
-            const float y0 = (a.y - o.y) * iy, y1 = (b.y - o.y) * iy;
-            const float z0 = (a.z - o.z) * iz, z1 = (b.z - o.z) * iz;
-            const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
-            const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-            // miss, or the box starts beyond the current best hit (with slack for |d| != 1 and rounding)
-            if (!(tn <= tf) || (h.any && tn * 0.999f - 1e-3f > best_t)) {
-                i = __float_as_uint(a.w);
-                continue;
-            }
-            i = i + 1u;
-            prim = (int)__float_as_uint(b.w);
-            if (prim >= 0) break;
-        }
-        if (prim < 0) break;
-        prim &= 0x3FFFFFFF;                                  // bit 30 = primitive type (used by the walk + pairs path)
-        if (DEBUG_BVH) dbg_leaves++;
-        const Prim &P = s_prims[prim];                     // per-lane gather of the record (L1/L2)
-        f3 ro = o, rd;
-        float tc;
-        uint32_t face;
-        if (!candidateT<false>(P.type, P.inv, o, d, ro, rd, tc, face)) continue;
-        f3 ip;
-        const float t = hitPoint(P.fwd, o, ro, rd, tc, ip);
-        if (t > 0 && (!h.any || t < best_t || (t == best_t && (uint32_t)prim < best_g))) {
-            h.any = true;
-            best_t = t;
-            best_g = (uint32_t)prim;
-            best_face = face;
-            h.p = ip;
-        }
-    }
-    if (h.any) {
-        const Prim &P = s_prims[best_g];
-        h.material = P.material;
-        if (P.type == 0u) h.n = sphereNormal(h.p, mk(P.cx, P.cy, P.cz));
-        else {
-            const float4 fn = reinterpret_cast<const float4 *>(p.face_n)[best_g * 8u + best_face];
-            h.n = mk(fn.x, fn.y, fn.z);
-        }
-    }
-    if (DEBUG_BVH) {
-        // per ray: nodes, leaves; per wave: the longest lane (what the wave pays)
-        uint32_t mn = dbg_nodes, ml = dbg_leaves, mo = dbg_outer;
-        for (int s = 32; s > 0; s >>= 1) {
-            mn = max(mn, (uint32_t)__shfl_xor((int)mn, s));
-            ml = max(ml, (uint32_t)__shfl_xor((int)ml, s));
-            mo = max(mo, (uint32_t)__shfl_xor((int)mo, s));
-        }
-        atomicAdd(&p.st->dbg[0], (unsigned long long)dbg_nodes);
-        atomicAdd(&p.st->dbg[1], (unsigned long long)dbg_leaves);
-        atomicAdd(&p.st->dbg[2], 1ull);
-        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {
-            atomicAdd(&p.st->dbg[3], (unsigned long long)mn);
-            atomicAdd(&p.st->dbg[4], (unsigned long long)ml);
-            atomicAdd(&p.st->dbg[5], (unsigned long long)mo);
-            atomicAdd(&p.st->dbg[6], 1ull);
-        }
-        (void)dbg_inner_wave;
-    }
-    h.prim = best_g;
-    h.t = best_t;
-    return h;
-}
-
-// wave-private LDS scratch of the hit queue
-struct WaveQueue {
-    float4 *rec;                  // [QCAP][2]: (ro.xyz, rd.x) (rd.y, rd.z, t, meta)
-    unsigned long long *key;      // [64] per owner lane: min over candidates of (distance bits << 32 | prim << 8)
-    float4 *best;                 // [64] per owner lane: (hit point xyz, meta) of the current minimum
-    float4 *org;                  // [64] per owner lane: ray origin
-};
-static constexpr uint32_t QCAP = 128;                                  // >= 63 pending + 64 appended
-static constexpr uint32_t WAVE_QUEUE_BYTES = QCAP * 32 + 64 * 8 + 64 * 16 + 64 * 16;
-static constexpr unsigned long long KEY_NONE = ~0ull;
-
-__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
-
-// Must be entered by all 64 lanes of the wave (lanes without a ray pass valid = false): lanes are consumers
-// of queued candidates independently of their own ray.
-template <bool FIRST>
-__device__ __forceinline__ Hit nearestHitQueued(const KParams &p, const Prim *s_prims, const WaveQueue q, f3 o, f3 d,
-                                                bool valid, uint32_t lane)
-{
-    q.key[lane] = KEY_NONE;
-    q.org[lane] = make_float4(o.x, o.y, o.z, 0.0f);
-    wave_lds_fence();
-    uint32_t qhead = 0, qtail = 0;                       // wave-uniform
-    const bool eye_cull = FIRST && p.eye_cull != 0;
-    const f3 dinv = eye_cull ? approxInverse(d) : mk(0, 0, 0);
-    for (int g = 0; g <= p.nG; ++g) {
-        if (g < p.nG && !(eye_cull && waveMissesBoxFromEye(p.box_eye, g, dinv, valid))) {
-            // candidate test: wave-uniform primitive (type + inverse transform through the scalar unit)
-            const_u32_ptr hp = (const_u32_ptr)(uintptr_t)(p.prims + g);
-            const uint32_t type = hp[0];
-            float inv[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) inv[k] = __uint_as_float(hp[4 + k]);
-            f3 ro = FIRST ? load_ro_eye(p.ro_eye, g) : mk(0, 0, 0), rd = mk(0, 0, 0);
-            float t = 0.0f;
-            uint32_t face = 0u;
-            const bool cand = valid && candidateT<FIRST>(type, inv, o, d, ro, rd, t, face);
-            const uint64_t mask = __ballot(cand);
-            if (mask != 0ull) {
-                if (cand) {
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                    const uint32_t pos = (qtail + rank) & (QCAP - 1u);
-                    const uint32_t meta = lane | ((uint32_t)g << 8) | (face << 28);
-                    q.rec[2 * pos] = make_float4(ro.x, ro.y, ro.z, rd.x);
-                    q.rec[2 * pos + 1] = make_float4(rd.y, rd.z, t, __uint_as_float(meta));
-                }
-                qtail += (uint32_t)__popcll(mask);
-            }
-        }
-        const uint32_t pending = qtail - qhead;
-        if (pending >= 64u || (g == p.nG && pending > 0u)) {
-            // hit work on a batch of candidates: lane l takes candidate qhead + l, whoever owns it
-            const uint32_t nb = pending < 64u ? pending : 64u;
-            wave_lds_fence();
-            unsigned long long mykey = KEY_NONE;
-            uint32_t owner = 0u;
-            float4 mine = make_float4(0, 0, 0, 0);
-            if (lane < nb) {
-                const uint32_t pos = (qhead + lane) & (QCAP - 1u);
-                const float4 r0 = q.rec[2 * pos], r1 = q.rec[2 * pos + 1];
-                const uint32_t meta = __float_as_uint(r1.w);
-                owner = meta & 63u;
-                const uint32_t prim = (meta >> 8) & 0xFFFFFu;
-                const float4 *fw = reinterpret_cast<const float4 *>(s_prims[prim].fwd);
-                const float4 f0 = fw[0], f1 = fw[1], f2 = fw[2];
-                const float fwd[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
-                const float4 oo = q.org[owner];
-                f3 real;
-                const float dist = hitPoint(fwd, mk(oo.x, oo.y, oo.z), mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), r1.z, real);
-                if (dist > 0) {                              // same admission test as the direct path: t > 0
-                    mykey = ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned long long)(prim << 8);
-                    mine = make_float4(real.x, real.y, real.z, r1.w);
-                    __hip_atomic_fetch_min(&q.key[owner], mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                }
-            }
-            wave_lds_fence();
-            if (mykey != KEY_NONE && q.key[owner] == mykey) q.best[owner] = mine;   // unique writer: keys are unique
-            qhead += nb;
-            wave_lds_fence();
-        }
-    }
-    Hit h;
-    h.any = false;
-    h.material = 0;
-    h.prim = 0;
-    h.t = 0.0f;
-    h.p = mk(0, 0, 0);
-    h.n = mk(0, 0, 0);
-    const unsigned long long k = q.key[lane];
-    if (valid && k != KEY_NONE) {
-        const float4 b = q.best[lane];
-        const uint32_t meta = __float_as_uint(b.w);
-        const uint32_t prim = (meta >> 8) & 0xFFFFFu;
-        const uint32_t face = meta >> 28;
-        const Prim &P = s_prims[prim];                       // per-lane gather from the LDS copy
-        h.any = true;
-        h.prim = prim;
-        h.t = __uint_as_float((uint32_t)(k >> 32));
-        h.p = mk(b.x, b.y, b.z);
-        h.material = P.material;
-        if (P.type == 0u) {
-            const float4 c = *reinterpret_cast<const float4 *>(&P.cx);
-            h.n = sphereNormal(h.p, mk(c.x, c.y, c.z));
-        } else {
-            const float4 fn = reinterpret_cast<const float4 *>(s_prims + p.nG)[prim * 8u + face];   // face-normal table behind the records
-            h.n = mk(fn.x, fn.y, fn.z);
-        }
-    }
-    return h;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// GEOM_PAIR
-// ---------------------------------------------------------------------------------------------------------------
-struct PairQueue {
-    uint32_t *q[2];               // [QCAP] pending pairs, lane | prim << 8: [0] spheres, [1] boxes
-    unsigned long long *key;      // [64] per owner lane: min over hits of (distance bits << 32 | prim << 8)
-    float4 *best;                 // [64] per owner lane: (hit point xyz, meta) of the current minimum
-    float4 *org;                  // [64] per owner lane: the ray, (origin.xyz, direction.x) ...
-    float2 *dir;                  // [64] ... (direction.y, direction.z)
-    unsigned long long *dbg;
-};
-static constexpr uint32_t PAIR_QUEUE_BYTES = 2 * QCAP * 4 + 64 * 8 + 2 * 64 * 16 + 64 * 8;
-static_assert(PAIR_QUEUE_BYTES <= WAVE_QUEUE_BYTES, "the pair queue lives in the hit queue's LDS region");
-
-// one batch: lane l takes pair head + l of queue TYPE (0 sphere, 1 box), whoever owns it.  TYPE 2 = the last, mixed
-// batch of a chunk: lanes [0, nb) take the sphere queue's leftovers, lanes [nb, nb + nb2) the box queue's.
-template <uint32_t TYPE, bool FIRST>
-__device__ __forceinline__ void pairBatch(const KParams &p, const Prim *s_prims, const PairQueue &q, uint32_t head, uint32_t nb,
-                                          uint32_t lane, uint32_t head2 = 0u, uint32_t nb2 = 0u)
-{
-    wave_lds_fence();
-    unsigned long long mykey = KEY_NONE;
-    uint32_t owner = 0u;
-    float4 mine = make_float4(0, 0, 0, 0);
-    if (lane < nb + nb2) {
-        const uint32_t type = (TYPE == 2u) ? (lane < nb ? 0u : 1u) : TYPE;
-        const uint32_t e = (TYPE == 2u && lane >= nb) ? q.q[1][(head2 + lane - nb) & (QCAP - 1u)]
-                                                      : q.q[TYPE == 2u ? 0u : TYPE][(head + lane) & (QCAP - 1u)];
-        owner = e & 63u;
-        const uint32_t prim = e >> 8;
-        const float4 oo = q.org[owner];
-        const float2 dd = q.dir[owner];
-        const f3 o = mk(oo.x, oo.y, oo.z), d = mk(oo.w, dd.x, dd.y);
-        const float4 *iv = reinterpret_cast<const float4 *>(s_prims[prim].inv);
-        const float4 i0 = iv[0], i1 = iv[1], i2 = iv[2];
-        const float inv[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
-        f3 ro = o, rd;
-        if (FIRST) {                                         // camera rays: inverseTransform*(eye,1) comes from the host
-            const float4 re = reinterpret_cast<const float4 *>(p.ro_eye)[prim];
-            ro = mk(re.x, re.y, re.z);
-        }
-        float t;
-        uint32_t face;
-        const bool ch = candidateT<FIRST>(type, inv, o, d, ro, rd, t, face);
-        if (DEBUG_PAIR) { const uint64_t mm = __ballot(ch); if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicAdd((unsigned long long *)q.dbg + 2 + (TYPE & 1u), (unsigned long long)__popcll(mm)); }
-        if (ch) {
-            const float4 f0 = iv[3], f1 = iv[4], f2 = iv[5];          // fwd rows follow the inverse rows
-            const float fwd[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
-            f3 real;
-            const float dist = hitPoint(fwd, o, ro, rd, t, real);
-            if (dist > 0) {                                  // same admission test as the direct path: t > 0
-                mykey = ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned long long)(prim << 8);
-                mine = make_float4(real.x, real.y, real.z, __uint_as_float((prim << 8) | (face << 28)));
-                __hip_atomic_fetch_min(&q.key[owner], mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-        }
-    }
-    wave_lds_fence();
-    if (mykey != KEY_NONE && q.key[owner] == mykey) q.best[owner] = mine;   // unique writer: keys are unique
-    wave_lds_fence();
-}
-
-// Must be entered by all 64 lanes of the wave (lanes without a ray pass valid = false).
-template <bool FIRST>
-__device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const Prim *s_prims, const float4 *s_boxes, const PairQueue q,
-                                               f3 o, f3 d, bool valid, uint32_t lane)
-{
-    q.key[lane] = KEY_NONE;
-    q.org[lane] = make_float4(o.x, o.y, o.z, d.x);
-    q.dir[lane] = make_float2(d.y, d.z);
-    uint32_t head[2] = {0u, 0u}, tail[2] = {0u, 0u};        // wave-uniform
-    const uint64_t vmask = __ballot(valid);
-    const f3 dinv = approxInverse(d);
-    // slab distances as fma(plane, 1/d, -o/d): one instruction per plane; against (plane - o)/d this moves a plane by
-    // less than 1.2e-6 |o|, far inside the boxes' padding
-    const f3 oinv = FIRST ? mk(0, 0, 0) : mk(-(o.x * dinv.x), -(o.y * dinv.y), -(o.z * dinv.z));
-    for (int g = 0; g < p.nG; ++g) {
-        const_u32_ptr hp = (const_u32_ptr)(uintptr_t)(p.prims + g);
-        const uint32_t type = hp[0];
-        if (type > 1u) continue;                             // MESH: never has geometry
-        // padded world box of the primitive against this lane's ray (camera rays: box relative to the shared eye), through
-        // an LDS broadcast read: VGPR operands keep the six fma at the full VALU rate (SGPR operands halve it)
-        const float4 lo4 = s_boxes[2 * g], hi4 = s_boxes[2 * g + 1];
-        const f3 lo = mk(lo4.x, lo4.y, lo4.z), hi = mk(hi4.x, hi4.y, hi4.z);
-        const float x0 = __builtin_fmaf(lo.x, dinv.x, oinv.x), x1 = __builtin_fmaf(hi.x, dinv.x, oinv.x);
-        const float y0 = __builtin_fmaf(lo.y, dinv.y, oinv.y), y1 = __builtin_fmaf(hi.y, dinv.y, oinv.y);
-        const float z0 = __builtin_fmaf(lo.z, dinv.z, oinv.z), z1 = __builtin_fmaf(hi.z, dinv.z, oinv.z);
-        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
-        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-        // the compare's lane mask straight from v_cmp, and back into a predicate without VALU work
-        const uint64_t mask = __builtin_amdgcn_fcmpf(tn, tf, FCMP_OLE) & vmask;
-        if (mask == 0ull) continue;
-        const bool pass = __builtin_amdgcn_inverse_ballot_w64(mask);
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        if (type == 0u) {                                    // wave-uniform
-            if (pass) q.q[0][(tail[0] + rank) & (QCAP - 1u)] = lane | ((uint32_t)g << 8);
-            tail[0] += (uint32_t)__popcll(mask);
-            if (tail[0] - head[0] >= 64u) { pairBatch<0u, FIRST>(p, s_prims, q, head[0], 64u, lane); head[0] += 64u; }
-        } else {
-            if (pass) q.q[1][(tail[1] + rank) & (QCAP - 1u)] = lane | ((uint32_t)g << 8);
-            tail[1] += (uint32_t)__popcll(mask);
-            if (tail[1] - head[1] >= 64u) { pairBatch<1u, FIRST>(p, s_prims, q, head[1], 64u, lane); head[1] += 64u; }
-        }
-    }
-    const uint64_t dbg_valid = DEBUG_PAIR ? __ballot(valid) : 0ull;
-    if (DEBUG_PAIR && lane == 0) {
-        atomicAdd(&p.st->dbg[0], (unsigned long long)tail[0]);
-        atomicAdd(&p.st->dbg[1], (unsigned long long)tail[1]);
-        atomicAdd(&p.st->dbg[4], (unsigned long long)__popcll(dbg_valid));
-        atomicAdd(&p.st->dbg[5], (unsigned long long)((tail[0] + 63) / 64 + (tail[1] + 63) / 64));
-        atomicAdd(&p.st->dbg[6], 1ull);
-    }
-    const uint32_t left0 = tail[0] - head[0], left1 = tail[1] - head[1];      // both < 64
-    if (left0 != 0u && left1 != 0u && left0 + left1 <= 64u) {
-        pairBatch<2u, FIRST>(p, s_prims, q, head[0], left0, lane, head[1], left1);   // one mixed batch instead of two partial ones
-    } else {
-        if (left0 != 0u) pairBatch<0u, FIRST>(p, s_prims, q, head[0], left0, lane);
-        if (left1 != 0u) pairBatch<1u, FIRST>(p, s_prims, q, head[1], left1, lane);
-    }
-    wave_lds_fence();
-    Hit h;
-    h.any = false;
-    h.material = 0;
-    h.prim = 0;
-    h.t = 0.0f;
-    h.p = mk(0, 0, 0);
-    h.n = mk(0, 0, 0);
-    const unsigned long long k = q.key[lane];
-    if (valid && k != KEY_NONE) {
-        const float4 b = q.best[lane];
-        const uint32_t meta = __float_as_uint(b.w);
-        const uint32_t prim = (meta >> 8) & 0xFFFFFu;
-        const uint32_t face = meta >> 28;
-        const Prim &P = s_prims[prim];                       // per-lane gather from the LDS copy
-        h.any = true;
-        h.prim = prim;
-        h.t = __uint_as_float((uint32_t)(k >> 32));
-        h.p = mk(b.x, b.y, b.z);
-        h.material = P.material;
-        if (P.type == 0u) {
-            const float4 c = *reinterpret_cast<const float4 *>(&P.cx);
-            h.n = sphereNormal(h.p, mk(c.x, c.y, c.z));
-        } else {
-            const float4 fn = reinterpret_cast<const float4 *>(s_prims + p.nG)[prim * 8u + face];   // face-normal table behind the records
-            h.n = mk(fn.x, fn.y, fn.z);
-        }
-    }
-    return h;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// GEOM_WALK_PAIR
-// ---------------------------------------------------------------------------------------------------------------
-// append the lanes' pairs (sphere / box flags are per lane, g = primitive index) and run a batch when one is full;
-// every lane of the wave must make the call
-template <bool FIRST>
-__device__ __forceinline__ void pushPairs(const KParams &p, const Prim *prims, const PairQueue &q, uint32_t (&head)[2],
-                                          uint32_t (&tail)[2], bool is_sphere, bool is_box, uint32_t g, uint32_t lane)
-{
-    const uint64_t m0 = __ballot(is_sphere), m1 = __ballot(is_box);
-    if (m0 != 0ull) {
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
-        if (is_sphere) q.q[0][(tail[0] + rank) & (QCAP - 1u)] = lane | (g << 8);
-        tail[0] += (uint32_t)__popcll(m0);
-        if (tail[0] - head[0] >= 64u) { pairBatch<0u, FIRST>(p, prims, q, head[0], 64u, lane); head[0] += 64u; }
-    }
-    if (m1 != 0ull) {
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
-        if (is_box) q.q[1][(tail[1] + rank) & (QCAP - 1u)] = lane | (g << 8);
-        tail[1] += (uint32_t)__popcll(m1);
-        if (tail[1] - head[1] >= 64u) { pairBatch<1u, FIRST>(p, prims, q, head[1], 64u, lane); head[1] += 64u; }
-    }
-}
-template <bool FIRST>
-__device__ __forceinline__ void flushPairs(const KParams &p, const Prim *prims, const PairQueue &q, uint32_t (&head)[2],
-                                           uint32_t (&tail)[2], uint32_t lane)
-{
-    const uint32_t left0 = tail[0] - head[0], left1 = tail[1] - head[1];      // both < 64
-    if (left0 != 0u && left1 != 0u && left0 + left1 <= 64u) {
-        pairBatch<2u, FIRST>(p, prims, q, head[0], left0, lane, head[1], left1);
-    } else {
-        if (left0 != 0u) pairBatch<0u, FIRST>(p, prims, q, head[0], left0, lane);
-        if (left1 != 0u) pairBatch<1u, FIRST>(p, prims, q, head[1], left1, lane);
-    }
-    head[0] = tail[0];
-    head[1] = tail[1];
-}
-
-// Must be entered by all 64 lanes of the wave.  prims: global records (gathered per lane through L1/L2).
-template <bool FIRST>
-__device__ __forceinline__ Hit nearestHitWalkPairs(const KParams &p, const Prim *prims, const float4 *s_nodes, const PairQueue q,
-                                                   f3 o, f3 d, bool valid, uint32_t lane)
-{
-    q.key[lane] = KEY_NONE;
-    q.org[lane] = make_float4(o.x, o.y, o.z, d.x);
-    q.dir[lane] = make_float2(d.y, d.z);
-    uint32_t head[2] = {0u, 0u}, tail[2] = {0u, 0u};        // wave-uniform
-    const f3 dinv = approxInverse(d);
-    const f3 oinv = mk(-(o.x * dinv.x), -(o.y * dinv.y), -(o.z * dinv.z));
-    // 1. the scene-spanning primitives (walls, big lights), wave-uniformly: box pre-test, pairs
-    for (int k = 0; k < p.nbig; ++k) {
-        const int g = p.big[k];
-        const_u32_ptr hp = (const_u32_ptr)(uintptr_t)(p.prims + g);
-        const uint32_t type = hp[0];
-        if (type > 1u) continue;
-        const_u32_ptr bq = (const_u32_ptr)(uintptr_t)(p.box_world + 8 * g);
-        const float x0 = __builtin_fmaf(__uint_as_float(bq[0]), dinv.x, oinv.x), x1 = __builtin_fmaf(__uint_as_float(bq[4]), dinv.x, oinv.x);
-        const float y0 = __builtin_fmaf(__uint_as_float(bq[1]), dinv.y, oinv.y), y1 = __builtin_fmaf(__uint_as_float(bq[5]), dinv.y, oinv.y);
-        const float z0 = __builtin_fmaf(__uint_as_float(bq[2]), dinv.z, oinv.z), z1 = __builtin_fmaf(__uint_as_float(bq[6]), dinv.z, oinv.z);
-        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
-        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-        const bool pass = valid && tn <= tf;
-        pushPairs<FIRST>(p, prims, q, head, tail, pass && type == 0u, pass && type == 1u, (uint32_t)g, lane);
-    }
-    flushPairs<FIRST>(p, prims, q, head, tail, lane);
-    wave_lds_fence();
-    // 2. the hierarchy: box tests only, pruned by the distance of the best hit so far (reported distances fall short of
-    // the true ones by getPointOnRay's epsilon: the slack covers it), leaves become pairs
-    float tmax = __builtin_inff();
-    {
-        const unsigned long long k0 = q.key[lane];
-        if (k0 != KEY_NONE) tmax = __uint_as_float((uint32_t)(k0 >> 32));
-    }
-    const uint32_t nn = (uint32_t)p.nnodes;
-    uint32_t i = valid ? 0u : nn;
-    uint32_t dbg_nodes = 0, dbg_leaves = 0, dbg_outer = 0, dbg_prev = 0, dbg_trips = 0;
-    for (;;) {
-        // A lane keeps walking past the leaves it reaches (they need no work here) and only stops when it has collected
-        // four or left the tree: breaking at every leaf would make the wave wait for its slowest lane once per leaf
-        // (measured: 141 loop trips per wave against 62 for the longest single walk).
-        int l0 = -1, l1 = -1, l2 = -1, l3 = -1;
-        if (DEBUG_BVH) dbg_outer++;
-        while (i < nn) {
-            if (DEBUG_BVH) dbg_nodes++;
-            const float4 a = s_nodes[2 * i], b = s_nodes[2 * i + 1];
-            const float x0 = __builtin_fmaf(a.x, dinv.x, oinv.x), x1 = __builtin_fmaf(b.x, dinv.x, oinv.x);
-            const float y0 = __builtin_fmaf(a.y, dinv.y, oinv.y), y1 = __builtin_fmaf(b.y, dinv.y, oinv.y);
-            const float z0 = __builtin_fmaf(a.z, dinv.z, oinv.z), z1 = __builtin_fmaf(b.z, dinv.z, oinv.z);
-            const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
-            const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-            if (!(tn <= tf) || tn * 0.999f - 1e-3f > tmax) {
-                i = __float_as_uint(a.w);
-                continue;
-            }
-            i = i + 1u;
-            const int pr = (int)__float_as_uint(b.w);
-            if (pr >= 0) {
-                l3 = l2; l2 = l1; l1 = l0; l0 = pr;
-                if (l3 >= 0) break;
-            }
-        }
-        const bool leaf = l0 >= 0;
-        if (DEBUG_BVH) dbg_leaves += (l0 >= 0) + (l1 >= 0) + (l2 >= 0) + (l3 >= 0);
-        if (DEBUG_BVH) {
-            uint32_t r = dbg_nodes - dbg_prev;
-            dbg_prev = dbg_nodes;
-            for (int s = 32; s > 0; s >>= 1) r = max(r, (uint32_t)__shfl_xor((int)r, s));
-            dbg_trips += r;
-        }
-        if (__ballot(leaf) == 0ull) break;                   // every lane has left the tree
-        const uint32_t done_before = head[0] + head[1];
-        {
-            const uint32_t type = (uint32_t)l0 >> 30, g = (uint32_t)l0 & 0x3FFFFFFFu;
-            pushPairs<FIRST>(p, prims, q, head, tail, l0 >= 0 && type == 0u, l0 >= 0 && type == 1u, g, lane);
-        }
-        if (__ballot(l1 >= 0) != 0ull) {
-            const uint32_t type = (uint32_t)l1 >> 30, g = (uint32_t)l1 & 0x3FFFFFFFu;
-            pushPairs<FIRST>(p, prims, q, head, tail, l1 >= 0 && type == 0u, l1 >= 0 && type == 1u, g, lane);
-        }
-        if (__ballot(l2 >= 0) != 0ull) {
-            const uint32_t type = (uint32_t)l2 >> 30, g = (uint32_t)l2 & 0x3FFFFFFFu;
-            pushPairs<FIRST>(p, prims, q, head, tail, l2 >= 0 && type == 0u, l2 >= 0 && type == 1u, g, lane);
-        }
-        if (__ballot(l3 >= 0) != 0ull) {
-            const uint32_t type = (uint32_t)l3 >> 30, g = (uint32_t)l3 & 0x3FFFFFFFu;
-            pushPairs<FIRST>(p, prims, q, head, tail, l3 >= 0 && type == 0u, l3 >= 0 && type == 1u, g, lane);
-        }
-        if (head[0] + head[1] != done_before) {              // a batch ran: the bound may have come down
-            const unsigned long long k1 = q.key[lane];
-            if (k1 != KEY_NONE) tmax = __uint_as_float((uint32_t)(k1 >> 32));
-        }
-    }
-    flushPairs<FIRST>(p, prims, q, head, tail, lane);
-    wave_lds_fence();
-    if (DEBUG_BVH) {
-        uint32_t mn = dbg_nodes, ml = dbg_leaves, mo = dbg_outer;
-        for (int s = 32; s > 0; s >>= 1) {
-            mn = max(mn, (uint32_t)__shfl_xor((int)mn, s));
-            ml = max(ml, (uint32_t)__shfl_xor((int)ml, s));
-            mo = max(mo, (uint32_t)__shfl_xor((int)mo, s));
-        }
-        if (valid) { atomicAdd(&p.st->dbg[0], (unsigned long long)dbg_nodes); atomicAdd(&p.st->dbg[1], (unsigned long long)dbg_leaves); atomicAdd(&p.st->dbg[2], 1ull); }
-        if (lane == 0) {
-            atomicAdd(&p.st->dbg[3], (unsigned long long)dbg_trips);
-            atomicAdd(&p.st->dbg[4], (unsigned long long)ml);
-            atomicAdd(&p.st->dbg[5], (unsigned long long)mo);
-            atomicAdd(&p.st->dbg[6], 1ull);
-            atomicAdd(&p.st->dbg[7], (unsigned long long)(tail[0] + tail[1]));
-        }
-    }
-    Hit h;
-    h.any = false;
-    h.material = 0;
-    h.prim = 0;
-    h.t = 0.0f;
-    h.p = mk(0, 0, 0);
-    h.n = mk(0, 0, 0);
-    const unsigned long long k = q.key[lane];
-    if (valid && k != KEY_NONE) {
-        const float4 b = q.best[lane];
-        const uint32_t meta = __float_as_uint(b.w);
-        const uint32_t prim = (meta >> 8) & 0xFFFFFu;
-        const uint32_t face = meta >> 28;
-        const Prim &P = prims[prim];
-        h.any = true;
-        h.prim = prim;
-        h.t = __uint_as_float((uint32_t)(k >> 32));
-        h.p = mk(b.x, b.y, b.z);
-        h.material = P.material;
-        if (P.type == 0u) h.n = sphereNormal(h.p, mk(P.cx, P.cy, P.cz));
-        else {
-            const float4 fn = reinterpret_cast<const float4 *>(p.face_n)[prim * 8u + face];
-            h.n = mk(fn.x, fn.y, fn.z);
-        }
-    }
-    return h;
-}
-
-// nearest hit of (o, d) for the lanes with want == true, by the GEOM path.  Every lane of the wave must make the call
-// (the hit queue uses all 64 lanes as workers whatever their own ray).
-template <int GEOM, bool FIRST>
-__device__ __forceinline__ Hit nearestHit(const KParams &p, const Prim *s_prims, const float4 *s_nodes, const WaveQueue &wq,
-                                          f3 o, f3 d, bool want, uint32_t lane)
-{
-    if (GEOM == GEOM_QUEUE) return nearestHitQueued<FIRST>(p, s_prims, wq, o, d, want, lane);
-    if (GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR) {
-        PairQueue pq;
-        unsigned char *b = reinterpret_cast<unsigned char *>(wq.rec);         // same LDS region as the hit queue
-        pq.q[0] = reinterpret_cast<uint32_t *>(b);
-        pq.q[1] = reinterpret_cast<uint32_t *>(b + QCAP * 4);
-        pq.key = reinterpret_cast<unsigned long long *>(b + 2 * QCAP * 4);
-        pq.best = reinterpret_cast<float4 *>(b + 2 * QCAP * 4 + 64 * 8);
-        pq.org = reinterpret_cast<float4 *>(b + 2 * QCAP * 4 + 64 * 8 + 64 * 16);
-        pq.dir = reinterpret_cast<float2 *>(b + 2 * QCAP * 4 + 64 * 8 + 2 * 64 * 16);
-        pq.dbg = p.st->dbg;
-        if (GEOM == GEOM_WALK_PAIR) return nearestHitWalkPairs<FIRST>(p, p.prims, s_nodes, pq, o, d, want, lane);
-        return nearestHitPairs<FIRST>(p, s_prims, s_nodes, pq, o, d, want, lane);
-    }
-    Hit h;
-    h.any = false;
-    h.material = 0;
-    h.prim = 0;
-    h.t = 0.0f;
-    h.p = mk(0, 0, 0);
-    h.n = mk(0, 0, 0);
-    if (GEOM == GEOM_BVH) {
-        if (want) h = nearestHitBvh<FIRST>(p, p.prims, s_nodes, o, d);
-    } else {
-        if (want) h = nearestHitDirect<(GEOM == GEOM_LDS ? GEOM_LDS : GEOM_SCALAR), FIRST>(p, s_prims, o, d);
-    }
-    return h;
-}
-
-// global pixel index (x + y*W of the frame: what the RNG streams are keyed on) of tile-local pixel pl
-__device__ __forceinline__ uint32_t globalPixel(const KParams &p, uint32_t pl)
-{
-    if (p.strip_span == 0u) return pl + p.pix_offset;
-    const uint32_t j = (uint32_t)(((unsigned long long)pl * p.strip_magic) >> p.strip_shift);     // pl / strip_span
-    return pl + p.strip_span * (j * (p.strip_world - 1u) + p.strip_rank);
-}
-
-// COMPACT: 0 = rays keep their slot (validation / ablation), 1 = per-wave reservation on sharded counters
-// (no workgroup barrier), 2 = LDS scan over the workgroup's waves + one atomic per workgroup.
-// NEE: explicit light sampling at diffuse vertices (pt_options.direct_light).  A ray then carries in bit 31 of its
-// pixel word whether its previous vertex sampled the lights (a light hit by chance adds nothing), the radiance planes
-// accumulate along the path (every path initialises its entry at bounce 0), and each chunk makes a second pass through
-// the nearest-hit machinery for the shadow rays.
-// 5 waves per SIMD (<= 96 VGPRs) is where the plain kernels sit and what hides their LDS / pool latency: ask for it, so
-// that a few registers more do not silently drop a wave (4 waves: -5 %).
-template <int WG, bool FIRST, int GEOM, int COMPACT, bool NEE = false>
-__global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(const KParams p, const int bounce)
-{
-    constexpr int NW = WG / 64;
-    constexpr bool PRIMS_IN_LDS = (GEOM == GEOM_LDS || GEOM == GEOM_QUEUE || GEOM == GEOM_PAIR);   // GEOM_BVH gathers records from global memory (L1/L2)
-    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
-    // LDS carve: [prims nG*128 B (GEOM 1,2)] [per-wave hit queues (GEOM 2)] [material planes] [scan scratch]
-    Prim *s_prims = reinterpret_cast<Prim *>(smem);
-    const int prim_bytes = PRIMS_IN_LDS ? p.nG * (int)(sizeof(Prim) + 128) : 0;      // records, then 8 face normals each
-    const float4 *s_nodes = reinterpret_cast<const float4 *>(smem + prim_bytes);
-    // pair queue: the same region holds the primitives' padded boxes (2 float4 each; relative to the eye for camera rays)
-    const int node_bytes = (GEOM == GEOM_BVH || GEOM == GEOM_WALK_PAIR) ? p.nnodes * (int)sizeof(BvhNode)
-                                                                        : (GEOM == GEOM_PAIR ? p.nG * 32 * (NEE ? 2 : 1) : 0);
-    unsigned char *s_queue = smem + prim_bytes + node_bytes;
-    constexpr int WAVE_LDS = (GEOM == GEOM_QUEUE) ? (int)WAVE_QUEUE_BYTES
-                             : ((GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR) ? (int)PAIR_QUEUE_BYTES : 0);
-    const int queue_bytes = NW * WAVE_LDS;
-    float *s_mats = reinterpret_cast<float *>(s_queue + queue_bytes);
-    const int mat_words = (p.nM * M_PLANES + 3) & ~3;
-    uint32_t *s_scan = reinterpret_cast<uint32_t *>(s_mats + mat_words);   // [2][NW] wave totals, [2] bases
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: chunk bookkeeping runs on the scalar unit
-
-    WaveQueue wq;
-    {
-        unsigned char *b = s_queue + wave * WAVE_LDS;
-        wq.rec = reinterpret_cast<float4 *>(b);
-        wq.key = reinterpret_cast<unsigned long long *>(b + QCAP * 32);
-        wq.best = reinterpret_cast<float4 *>(b + QCAP * 32 + 64 * 8);
-        wq.org = reinterpret_cast<float4 *>(b + QCAP * 32 + 64 * 8 + 64 * 16);
-    }
-
-    if (PRIMS_IN_LDS) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(p.prims);
-        uint4 *dst = reinterpret_cast<uint4 *>(s_prims);
-        for (int k = tid; k < p.nG * 8; k += WG) dst[k] = src[k];
-        const uint4 *fsrc = reinterpret_cast<const uint4 *>(p.face_n);
-        for (int k = tid; k < p.nG * 8; k += WG) dst[p.nG * 8 + k] = fsrc[k];
-    }
-    if (GEOM == GEOM_PAIR) {
-        const uint4 *src = reinterpret_cast<const uint4 *>((FIRST && !(p.lens_radius > 0.0f)) ? p.box_eye : p.box_world);
-        uint4 *dst = reinterpret_cast<uint4 *>(smem + prim_bytes);
-        for (int k = tid; k < p.nG * 2; k += WG) dst[k] = src[k];
-        if (NEE) {                                           // shadow rays start anywhere: world boxes, second half
-            const uint4 *srcw = reinterpret_cast<const uint4 *>(p.box_world);
-            for (int k = tid; k < p.nG * 2; k += WG) dst[p.nG * 2 + k] = srcw[k];
-        }
-    }
-    if (GEOM == GEOM_BVH || GEOM == GEOM_WALK_PAIR) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(p.bvh);
-        uint4 *dst = reinterpret_cast<uint4 *>(smem + prim_bytes);
-        for (int k = tid; k < p.nnodes * 2; k += WG) dst[k] = src[k];
-    }
-    for (int k = tid; k < p.nM * M_PLANES; k += WG) s_mats[k] = p.mats[k];
-    __syncthreads();
-
-    IterState *st = p.st;
-    const uint32_t iter = st->iter;
-    unsigned long long clk0 = 0, rt0 = 0;
-    if (bounce == 1 && blockIdx.x == 0 && tid == 0) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
-    const RayPool in = p.pool[bounce & 1];
-    const RayPool out = p.pool[(bounce + 1) & 1];
-    const bool last = (bounce == p.depth - 1);
-    // Up to MAXSLOT consecutive iterations are in flight in one launch sequence; a ray carries its iteration
-    // slot in the top bits of its pixel word.  The per-(iteration, bounce) stream keys are wave-uniform.
-    // The per-(iteration, bounce) stream keys sit in an LDS table indexed by the slot: one ds_read per ray instead of a
-    // compare/select chain over the slots (v_cmp / v_cndmask issue at half rate).
-    __shared__ uint32_t s_key[MAXSLOT], s_key_cam[MAXSLOT];
-    if (tid < MAXSLOT) {
-        s_key[tid] = stream_key(iter + (uint32_t)tid, (uint32_t)bounce + 1u, p.seed);
-        if (FIRST) s_key_cam[tid] = stream_key(iter + (uint32_t)tid, 0u, p.seed);
-    }
-    const uint32_t npix = (uint32_t)p.npix;
-
-    // Input: the live rays of this bounce sit in up to NSHARD dense segments of the pool (one per reservation
-    // counter).  A wave works on 64-ray chunks; chunk -> (segment, offset) is wave-uniform scalar arithmetic.
-    // The per-segment ray counts sit in a small LDS table; a wave visits its chunks in increasing order, so it keeps a
-    // cursor (segment, first chunk of it, rays in it) in scalar registers and only touches the table when it crosses
-    // into the next segment.
-    __shared__ uint32_t s_segn[NSHARD];
-    if (tid < NSHARD) {
-        uint32_t ns = 0;
-        if (FIRST || COMPACT == 0) ns = (tid == 0) ? (uint32_t)p.npix * st->nslot : 0u;
-        else if (tid < p.nshard) ns = st->counts[cnt_index(bounce, tid)];
-        s_segn[tid] = ns;
-    }
-    __syncthreads();
-    uint32_t total_chunks = 0;
-#pragma unroll
-    for (int k = 0; k < NSHARD; ++k) total_chunks += ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_segn[k]) + 63u) >> 6;
-    struct Cursor { uint32_t sh, c0, nseg; };
-    // the segment this wave (COMPACT 1) / workgroup (COMPACT 2) appends its survivors to
-    const uint32_t gwave = blockIdx.x * NW + wave;
-    const uint32_t myshard = (COMPACT == 1 ? gwave : blockIdx.x) & (uint32_t)(p.nshard - 1);
-    uint32_t *const out_counter = &st->counts[cnt_index(bounce + 1, myshard)];
-    const uint32_t out_base = myshard * p.segcap;
-
-    uint32_t live_count = 0;      // COMPACT 0: rays this wave found alive on entry
-    uint32_t shadow_count = 0;    // NEE: shadow rays this wave traced
-    int round = 0;
-    unsigned long long ph[5] = {0, 0, 0, 0, 0};
-    // pool slot of this lane in the chunk workgroup-round R2 gives this wave, and whether there is a ray in it
-    auto locate = [&](Cursor &cu, uint32_t R2, uint32_t &slot_i) -> bool {
-        const uint32_t chunk = R2 * NW + wave;
-        while (cu.sh + 1u < (uint32_t)NSHARD && chunk >= cu.c0 + ((cu.nseg + 63u) >> 6)) {
-            cu.c0 += (cu.nseg + 63u) >> 6;
-            cu.sh += 1u;
-            cu.nseg = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_segn[cu.sh]);
-        }
-        const uint32_t idx = (chunk - cu.c0) * 64u + lane;       // index inside the segment
-        slot_i = cu.sh * p.segcap + idx;                          // pool slot (FIRST / COMPACT 0: sh == 0, i == idx)
-        return chunk < total_chunks && idx < cu.nseg;
-    };
-    Cursor cur = {0u, 0u, (uint32_t)__builtin_amdgcn_readfirstlane((int)s_segn[0])};
-    for (uint32_t R = blockIdx.x; R * NW < total_chunks; R += gridDim.x, ++round) {     // workgroup-uniform trip count
-        const unsigned long long tc0 = DEBUG_PHASE ? __builtin_amdgcn_s_memtime() : 0ull;
-        uint32_t i;
-        bool valid = locate(cur, R, i);
-        const bool in_pool = valid;                               // the slot exists (COMPACT 0: it may hold a dead ray)
-        f3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(1, 1, 1);
-        uint32_t pix = 0;
-        if (FIRST) {
-            if (valid) {
-                // raycastFromCameraKernel: jittered pinhole ray through tile-local pixel pl of iteration slot
-                // With at least 64 pixels per slot, 64 consecutive ray indices meet at most one slot boundary: the slot
-                // of the chunk's first ray on the scalar unit, one compare per lane for the step.  Tiny tiles (a chunk
-                // spans several slots) take the general count.
-                uint32_t slot = 0;
-                if (npix >= 64u) {
-                    const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(i - (uint32_t)lane));
-                    uint32_t slot_lo = 0;
-#pragma unroll
-                    for (uint32_t k = 1; k < (uint32_t)MAXSLOT; ++k) slot_lo += (base >= k * npix) ? 1u : 0u;
-                    slot = slot_lo + ((i >= (slot_lo + 1u) * npix) ? 1u : 0u);
-                } else {
-#pragma unroll
-                    for (uint32_t k = 1; k < (uint32_t)MAXSLOT; ++k) slot += (i >= k * npix) ? 1u : 0u;
-                }
-                const uint32_t pl = i - slot * npix;
-                pix = pl | (slot << SLOT_SHIFT);
-                const uint32_t gp = globalPixel(p, pl);
-                const uint32_t y = (uint32_t)(((unsigned long long)gp * p.w_magic) >> p.w_shift);   // gp / W
-                const uint32_t x = gp - y * (uint32_t)p.W;
-                const uint32_t kc = s_key_cam[slot];
-                uint32_t s = minstd_seed(wang_hash(gp ^ kc));
-                s = minstd_next(s);
-                const float jx = u01_of(s);
-                s = minstd_next(s);
-                const float jy = u01_of(s);
-                const float sx = ((float)x + jx) / p.resx;
-                const float sy = ((float)y + jy) / p.resy;
-                const f3 eye = mk(p.eye[0], p.eye[1], p.eye[2]);
-                const f3 P = (mk(p.M[0], p.M[1], p.M[2]) + (1.0f - 2.0f * sx) * mk(p.H[0], p.H[1], p.H[2])) +
-                             (1.0f - 2.0f * sy) * mk(p.V[0], p.V[1], p.V[2]);
-                o = eye;
-                d = normalize(P - eye);
-                if (p.lens_radius > 0.0f) {
-                    // thin lens (depth of field): the pinhole ray fixes the point in focus; start on the lens disc
-                    s = minstd_next(s);
-                    const float u1 = u01_of(s);
-                    s = minstd_next(s);
-                    const float u2 = u01_of(s);
-                    const float tf = p.focal_distance / dot(d, mk(p.vn[0], p.vn[1], p.vn[2]));
-                    const f3 Pf = eye + tf * d;
-                    const float rr = p.lens_radius * sqrt_rn(u1);
-                    const float around = (float)((double)u2 * 6.2831853071795864769252867665590057683943);
-                    float sn, cs;
-                    sincos_poly(around, sn, cs);
-                    o = eye + ((rr * cs) * mk(p.A[0], p.A[1], p.A[2]) + (rr * sn) * mk(p.B[0], p.B[1], p.B[2]));
-                    d = normalize(Pf - o);
-                }
-            }
-        } else {
-            if (valid) {
-                const float2 c = in.c[i];
-                pix = __float_as_uint(c.y);
-                if (COMPACT == 0 && pix == DEAD) valid = false;
-                if (valid) {
-                    const float4 a = in.a[i];
-                    const float4 b = in.b[i];
-                    o = mk(a.x, a.y, a.z);
-                    d = mk(a.w, b.x, b.y);
-                    T = mk(b.z, b.w, c.x);
-                }
-            }
-        }
-        if (COMPACT == 0) live_count += (uint32_t)__popcll(__ballot(valid));
-
-        bool alive = false;
-        const unsigned long long c1 = DEBUG_PHASE ? __builtin_amdgcn_s_memtime() : 0ull;
-        // camera rays share the eye (host-side eye transforms and eye-relative boxes) unless a lens spreads their origins
-        const Hit h = (FIRST && p.lens_radius > 0.0f) ? nearestHit<GEOM, false>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane)
-                                                      : nearestHit<GEOM, FIRST>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane);
-        const unsigned long long c2 = DEBUG_PHASE ? __builtin_amdgcn_s_memtime() : 0ull;
-        f3 L = mk(0, 0, 0);               // radiance this vertex adds to the path's sample
-        // direct lighting: the shadow ray this lane wants traced and what it is worth if the light is visible
-        bool want_shadow = false;
-        f3 so = mk(0, 0, 0), sd = mk(0, 0, 0), Ld = mk(0, 0, 0);
-        uint32_t lprim = 0;
-        float ldist = 0.0f;
-        if (valid) {
-            if (h.any) {
-                const uint32_t m = h.material;
-                const float emit = s_mats[M_EMIT * p.nM + m];
-                if (emit > 0.0f) {
-                    if (!NEE || (pix >> 31) == 0u) {
-                        const f3 col = mk(s_mats[M_CR * p.nM + m], s_mats[M_CG * p.nM + m], s_mats[M_CB * p.nM + m]);
-                        L = emit * (T * col);
-                    }
-                } else if (!last || NEE) {
-                    // calculateBSDF: pick the lobe, build the next ray
-                    const uint32_t slot = NEE ? ((pix >> SLOT_SHIFT) & (uint32_t)(MAXSLOT - 1)) : (pix >> SLOT_SHIFT);
-                    const uint32_t kb = s_key[slot];
-                    uint32_t s = minstd_seed(wang_hash(globalPixel(p, pix & PIX_MASK) ^ kb));
-                    s = minstd_next(s);
-                    const float u_select = u01_of(s);
-                    s = minstd_next(s);
-                    const float xi1 = u01_of(s);
-                    s = minstd_next(s);
-                    const float xi2 = u01_of(s);
-                    s = minstd_next(s);
-                    const float u_rr = u01_of(s);
-
-                    const float ndotd = dot(h.n, d);
-                    const bool backside = ndotd > 0.0f;
-                    const f3 nf = backside ? -h.n : h.n;
-                    const float refr = s_mats[M_REFR * p.nM + m];
-                    const float refl = s_mats[M_REFL * p.nM + m];
-                    const bool diffuse = !(refr > 0.0f) && !(refl > 0.0f);
-                    if (NEE && diffuse) {
-                        // one light, one point on it (the reference's float-seeded samplers), one shadow ray;
-                        // estimator T*c/pi * Le * cos_x cos_y / d^2 * (area * number of lights)
-                        s = minstd_next(s);
-                        const float u_light = u01_of(s);
-                        s = minstd_next(s);
-                        const float u_seed = u01_of(s);
-                        int j = (int)(u_light * (float)p.nlights);
-                        if (j > p.nlights - 1) j = p.nlights - 1;
-                        lprim = (uint32_t)p.lights[j];
-                        const Prim *LP = PRIMS_IN_LDS ? &s_prims[lprim] : &p.prims[lprim];
-                        const uint4 hd = *reinterpret_cast<const uint4 *>(LP);           // type, material, area, pad
-                        const float4 *fw = reinterpret_cast<const float4 *>(LP->fwd);
-                        const float4 f0 = fw[0], f1 = fw[1], f2 = fw[2], cc = fw[3];   // fwd rows, (cx, cy, cz, bound)
-                        const float fwd[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
-                        f3 yl, nl;
-                        if (hd.x == 1u) {                            // cube light: thresholds and face normals from the table
-                            const float4 *tab = (PRIMS_IN_LDS ? reinterpret_cast<const float4 *>(s_prims + p.nG)
-                                                              : reinterpret_cast<const float4 *>(p.face_n)) + lprim * 8u;
-                            sampleCubeLightTab(fwd, tab, u_seed * 16777216.0f, yl, nl);
-                        } else {
-                            sampleLight(hd.x, fwd, mk(cc.x, cc.y, cc.z), u_seed * 16777216.0f, yl, nl);
-                        }
-                        so = h.p + 0.0002f * nf;
-                        const f3 wi = yl - so;
-                        const float d2 = dot(wi, wi);
-                        ldist = sqrt_rn(d2);
-                        sd = normalize(wi);
-                        const float cx = dot(nf, sd), cy = -dot(nl, sd);
-                        if (cx > 0.0f && cy > 0.0f) {
-                            want_shadow = true;
-                            const float G = (cx * cy) / d2;
-                            const float wgt = (G * (__uint_as_float(hd.z) * (float)p.nlights)) * 0.318309886f;
-                            const uint32_t lm = hd.y;
-                            const f3 col = mk(s_mats[M_CR * p.nM + m], s_mats[M_CG * p.nM + m], s_mats[M_CB * p.nM + m]);
-                            const f3 lcol = mk(s_mats[M_CR * p.nM + lm], s_mats[M_CG * p.nM + lm], s_mats[M_CB * p.nM + lm]);
-                            Ld = wgt * ((T * col) * (s_mats[M_EMIT * p.nM + lm] * lcol));
-                        }
-                    }
-                    if (!last) {
-                    f3 nd;
-                    f3 bias_n = nf;
-                    float bias = 0.0002f;                 // RAY_BIAS_AMOUNT, ref: src/utilities.h:26
-                    if (refr > 0.0f) {
-                        const float ior = s_mats[M_IOR * p.nM + m];
-                        const float n1 = backside ? ior : 1.0f;
-                        const float n2 = backside ? 1.0f : ior;
-                        const f3 rdir = reflectionDirection(nf, d);
-                        bool tir;
-                        const f3 tdir = transmissionDirection(nf, d, n1, n2, tir);
-                        const float Rf = fresnelReflectance(nf, d, n1, n2, tdir);
-                        if (p.absorption && backside) {
-                            // the segment that ends on the inner side of the surface ran through the medium
-                            const f3 sa = mk(s_mats[M_AR * p.nM + m], s_mats[M_AG * p.nM + m], s_mats[M_AB * p.nM + m]);
-                            if (sa.x != 0.0f || sa.y != 0.0f || sa.z != 0.0f) T = T * calculateTransmission(sa, h.t);
-                        }
-                        T = T * mk(s_mats[M_SR * p.nM + m], s_mats[M_SG * p.nM + m], s_mats[M_SB * p.nM + m]);
-                        if (u_select < Rf) nd = rdir;
-                        else {
-                            // transmitted: start beyond the surface.  h.p was pulled back by getPointOnRay's 1e-4
-                            // object-space epsilon (ref: src/intersections.h:46-48) = 1e-4/|inverseTransform*d| in
-                            // world units, more than the bias for objects scaled by > 2
-                            nd = tdir;
-                            bias_n = -nf;
-                            const Prim *HP = PRIMS_IN_LDS ? &s_prims[h.prim] : &p.prims[h.prim];
-                            const float4 *iv = reinterpret_cast<const float4 *>(HP->inv);
-                            const float4 i0 = iv[0], i1 = iv[1], i2 = iv[2];
-                            const float inv[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
-                            const f3 v = mulMV(inv, d, 0.0f);
-                            bias = 0.0002f + 1e-4f * rsqrt_rn(dot(v, v));
-                        }
-                    } else if (refl > 0.0f) {
-                        T = T * mk(s_mats[M_SR * p.nM + m], s_mats[M_SG * p.nM + m], s_mats[M_SB * p.nM + m]);
-                        nd = reflectionDirection(nf, d);
-                    } else {
-                        T = T * mk(s_mats[M_CR * p.nM + m], s_mats[M_CG * p.nM + m], s_mats[M_CB * p.nM + m]);
-                        nd = randomDirectionInHemisphere(nf, xi1, xi2);
-                    }
-                    o = h.p + bias * bias_n;
-                    d = nd;
-                    alive = true;
-                    if (p.rr_start >= 0 && bounce >= p.rr_start) {      // Russian roulette
-                        float q = T.x;
-                        if (T.y > q) q = T.y;
-                        if (T.z > q) q = T.z;
-                        q = (q < 0.05f) ? 0.05f : ((q > 1.0f) ? 1.0f : q);
-                        if (u_rr >= q) alive = false;
-                        else T = mk(T.x / q, T.y / q, T.z / q);
-                    }
-                    if (NEE) pix = (pix & 0x7FFFFFFFu) | (diffuse ? 0x80000000u : 0u);
-                    }
-                }
-            }
-        }
-        if (NEE) {
-            const uint64_t wmask = __ballot(want_shadow);
-            if (wmask != 0ull) {                              // wave-uniform
-                shadow_count += (uint32_t)__popcll(wmask);
-                const Hit hs = nearestHit<GEOM, false>(p, s_prims, (GEOM == GEOM_PAIR) ? s_nodes + 2 * p.nG : s_nodes, wq, so, sd,
-                                                       want_shadow, (uint32_t)lane);
-                if (want_shadow && hs.any && hs.prim == lprim) {
-                    const float tol = 1e-3f * ((ldist > 1.0f) ? ldist : 1.0f);
-                    if (fabsf(hs.t - ldist) <= tol) L = L + Ld;          // the sampled point itself is what the ray reached
-                }
-            }
-            if (valid) {
-                // the plane entry accumulates along the path: set at bounce 0, added to afterwards (exclusive owner)
-                float *lp = p.lbuf + 3u * ((size_t)((pix >> SLOT_SHIFT) & (uint32_t)(MAXSLOT - 1)) * npix + (size_t)(pix & PIX_MASK));
-                if (FIRST) {
-                    lp[0] = L.x;
-                    lp[1] = L.y;
-                    lp[2] = L.z;
-                } else if (L.x != 0.0f || L.y != 0.0f || L.z != 0.0f) {
-                    lp[0] = lp[0] + L.x;
-                    lp[1] = lp[1] + L.y;
-                    lp[2] = lp[2] + L.z;
-                }
-            }
-        } else if (valid && !alive) {
-            // the path ends here: its radiance sample goes to this iteration slot's plane; k_accumulate folds
-            // the planes into the running mean in iteration order once the launch sequence is done
-            float *lp = p.lbuf + 3u * ((size_t)(pix >> SLOT_SHIFT) * npix + (size_t)(pix & PIX_MASK));
-            lp[0] = L.x;
-            lp[1] = L.y;
-            lp[2] = L.z;
-        }
-
-        const unsigned long long c3 = DEBUG_PHASE ? __builtin_amdgcn_s_memtime() : 0ull;
-        if (DEBUG_PHASE) { ph[0] += c1 - tc0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[4] += 1; }
-        if (last) continue;      // wave-uniform: nothing survives the last bounce
-
-        if (COMPACT != 0) {
-            // stream compaction: wave ballot/mbcnt prefix, then a reservation in this wave's / workgroup's segment
-            const uint64_t mask = __ballot(alive);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            const uint32_t wtot = (uint32_t)__popcll(mask);
-            uint32_t dst;
-            if (COMPACT == 1 || NW == 1) {
-                uint32_t b = 0;
-                if (lane == 0 && wtot) b = atomicAdd(out_counter, wtot);
-                dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)b) + rank;
-            } else {
-                const int par = round & 1;
-                uint32_t *tot = s_scan + par * NW;
-                uint32_t *gbase = s_scan + 2 * NW + par;
-                if (lane == 0) tot[wave] = wtot;
-                __syncthreads();
-                if (tid == 0) {
-                    uint32_t sum = 0;
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) sum += tot[w];
-                    *gbase = sum ? atomicAdd(out_counter, sum) : 0u;
-                }
-                __syncthreads();
-                uint32_t off = *gbase;
-                for (int w = 0; w < wave; ++w) off += tot[w];
-                dst = off + rank;
-            }
-            dst += out_base;
-            if (alive) {
-                out.a[dst] = make_float4(o.x, o.y, o.z, d.x);
-                out.b[dst] = make_float4(d.y, d.z, T.x, T.y);
-                out.c[dst] = make_float2(T.z, __uint_as_float(pix));
-            }
-        } else {
-            // no compaction (validation / ablation mode): the ray keeps slot i, dead slots are tagged
-            if (in_pool) {
-                if (alive) {
-                    out.a[i] = make_float4(o.x, o.y, o.z, d.x);
-                    out.b[i] = make_float4(d.y, d.z, T.x, T.y);
-                    out.c[i] = make_float2(T.z, __uint_as_float(pix));
-                } else {
-                    out.c[i] = make_float2(0.0f, __uint_as_float(DEAD));
-                }
-            }
-        }
-    }
-    if (COMPACT == 0) {
-        if (lane == 0 && live_count) atomicAdd(&st->counts[cnt_index(bounce, 0)], live_count);
-    }
-    if (NEE) {
-        if (lane == 0 && shadow_count) atomicAdd(&st->shadow_rays, (unsigned long long)shadow_count);
-    }
-    if (DEBUG_PHASE && lane == 0) {
-        const int base = FIRST ? 0 : 4;
-        atomicAdd(&st->dbg[base + 0], ph[0]);
-        atomicAdd(&st->dbg[base + 1], ph[1]);
-        atomicAdd(&st->dbg[base + 2], ph[2]);
-        atomicAdd(&st->dbg[base + 3], ph[4]);
-    }
-    if (bounce == 1 && blockIdx.x == 0 && tid == 0) {      // clock diagnostics (one thread per launch)
-        st->clk[0] = __builtin_amdgcn_s_memtime() - clk0;
-        st->clk[1] = __builtin_amdgcn_s_memrealtime() - rt0;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // self-test of the short exact sqrt / reciprocal sequences (pt_device.h): every one of the 2^32 fp32 bit
@@ -1385,54 +218,40 @@ __global__ __launch_bounds__(256) void k_send_image_to_pbo(pt_uchar4 *pbo, const
 // ---------------------------------------------------------------------------------------------
 size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg)
 {
-    size_t prim = (cfg.geom == GEOM_LDS || cfg.geom == GEOM_QUEUE || cfg.geom == GEOM_PAIR) ? (size_t)p.nG * (sizeof(Prim) + 128) : 0;
+    size_t prim = (cfg.geom == GEOM_LDS || cfg.geom == GEOM_QUEUE || cfg.geom == GEOM_PAIR) ? (size_t)p.nG * 2 * sizeof(PrimPad) : 0;
     size_t queue = (size_t)(cfg.workgroup / 64) * (cfg.geom == GEOM_QUEUE ? WAVE_QUEUE_BYTES
-                                                   : ((cfg.geom == GEOM_PAIR || cfg.geom == GEOM_WALK_PAIR) ? PAIR_QUEUE_BYTES : 0));
+                                                   : ((cfg.geom == GEOM_PAIR || cfg.geom == GEOM_WALK_PAIR) ? PAIR_QUEUE_BYTES
+                                                      : (cfg.geom == GEOM_WALK4 ? PAIR_QUEUE_BYTES + WALK4_EXTRA_BYTES : 0)));
+    if (cfg.geom == GEOM_WALK4 && !PT_W4_GLOBAL) prim += ((size_t)p.nnodes4 * W4_FLOATS * 4 + 127) & ~(size_t)127;
     if (cfg.geom == GEOM_BVH || cfg.geom == GEOM_WALK_PAIR) prim += (size_t)p.nnodes * sizeof(BvhNode);
-    if (cfg.geom == GEOM_PAIR) prim += (size_t)p.nG * 32 * (cfg.nee ? 2 : 1);
+    // pair queue: one box per primitive (x2 with direct lighting) in the camera kernel, 4-wide records in the others;
+    // one figure for both kernels of a launch sequence
+    if (cfg.geom == GEOM_PAIR) prim += std::max((size_t)p.nG * 32 * (cfg.nee ? 2 : 1), ((size_t)p.npgroups * W4_FLOATS * 4 + 127) & ~(size_t)127);
     size_t mats = (size_t)((p.nM * M_PLANES + 3) & ~3) * sizeof(float);
     size_t scan = (size_t)((2 * (cfg.workgroup / 64) + 2 + 3) & ~3) * sizeof(uint32_t);
     static const size_t extra = getenv("PT_EXTRA_LDS") ? (size_t)atol(getenv("PT_EXTRA_LDS")) : 0;   // occupancy experiments
     return prim + queue + mats + scan + extra;
 }
 
-template <int WG, int GEOM, int COMPACT>
-static const void *bounce_fn(bool first)
-{
-    return first ? (const void *)k_bounce<WG, true, GEOM, COMPACT> : (const void *)k_bounce<WG, false, GEOM, COMPACT>;
-}
-
-template <int WG, int GEOM>
-static const void *bounce_fn_geom(bool first, int compact, int nee)
-{
-    if (nee) {
-        if (compact != 1) return nullptr;
-        return first ? (const void *)k_bounce<WG, true, GEOM, 1, true> : (const void *)k_bounce<WG, false, GEOM, 1, true>;
-    }
-    if (compact == 1) return bounce_fn<WG, GEOM, 1>(first);
-    if (compact == 2) return bounce_fn<WG, GEOM, 2>(first);
-    return bounce_fn<WG, GEOM, 0>(first);
-}
-
-template <int WG>
-static const void *bounce_fn_wg(bool first, int geom, int compact, int nee)
-{
-    if (geom == GEOM_WALK_PAIR) return bounce_fn_geom<WG, GEOM_WALK_PAIR>(first, compact, nee);
-    if (geom == GEOM_PAIR) return bounce_fn_geom<WG, GEOM_PAIR>(first, compact, nee);
-    if (geom == GEOM_BVH) return bounce_fn_geom<WG, GEOM_BVH>(first, compact, nee);
-    if (geom == GEOM_QUEUE) return bounce_fn_geom<WG, GEOM_QUEUE>(first, compact, nee);
-    if (geom == GEOM_LDS) return bounce_fn_geom<WG, GEOM_LDS>(first, compact, nee);
-    return bounce_fn_geom<WG, GEOM_SCALAR>(first, compact, nee);
-}
+// one translation unit per geometry path (pt_bounce_g<N>.hip)
+const void *bounce_kernel_g0(int workgroup, bool first, int compact, int nee);
+const void *bounce_kernel_g1(int workgroup, bool first, int compact, int nee);
+const void *bounce_kernel_g2(int workgroup, bool first, int compact, int nee);
+const void *bounce_kernel_g3(int workgroup, bool first, int compact, int nee);
+const void *bounce_kernel_g4(int workgroup, bool first, int compact, int nee);
+const void *bounce_kernel_g5(int workgroup, bool first, int compact, int nee);
+const void *bounce_kernel_g6(int workgroup, bool first, int compact, int nee);
 
 static const void *select_bounce(const LaunchCfg &cfg, bool first)
 {
-    switch (cfg.workgroup) {
-    case 64: return bounce_fn_wg<64>(first, cfg.geom, cfg.compact, cfg.nee);
-    case 128: return bounce_fn_wg<128>(first, cfg.geom, cfg.compact, cfg.nee);
-    case 256: return bounce_fn_wg<256>(first, cfg.geom, cfg.compact, cfg.nee);
-    case 512: return bounce_fn_wg<512>(first, cfg.geom, cfg.compact, cfg.nee);
-    case 1024: return bounce_fn_wg<1024>(first, cfg.geom, cfg.compact, cfg.nee);
+    switch (cfg.geom) {
+    case GEOM_SCALAR: return bounce_kernel_g0(cfg.workgroup, first, cfg.compact, cfg.nee);
+    case GEOM_LDS: return bounce_kernel_g1(cfg.workgroup, first, cfg.compact, cfg.nee);
+    case GEOM_QUEUE: return bounce_kernel_g2(cfg.workgroup, first, cfg.compact, cfg.nee);
+    case GEOM_BVH: return bounce_kernel_g3(cfg.workgroup, first, cfg.compact, cfg.nee);
+    case GEOM_PAIR: return bounce_kernel_g4(cfg.workgroup, first, cfg.compact, cfg.nee);
+    case GEOM_WALK_PAIR: return bounce_kernel_g5(cfg.workgroup, first, cfg.compact, cfg.nee);
+    case GEOM_WALK4: return bounce_kernel_g6(cfg.workgroup, first, cfg.compact, cfg.nee);
     default: return nullptr;
     }
 }

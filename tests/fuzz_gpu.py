@@ -38,7 +38,7 @@ def main():
         depth = int(rng.integers(1, 10))
         iters = int(rng.integers(1, 5))
         opts = dict(rr_start=int(rng.integers(-1, depth)), seed=int(rng.integers(0, 1000)))
-        gopts = dict(geom_path=int(rng.choice([0, 1, 2, 3, 4, 5, 6])), batch=int(rng.choice([0, 1, 2, 3, 7, 16])))
+        gopts = dict(geom_path=int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7])), batch=int(rng.choice([0, 1, 2, 3, 7, 16])))
         if rng.random() < 0.4:
             opts["direct_light"] = 1
         if rng.random() < 0.4:

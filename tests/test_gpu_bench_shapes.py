@@ -197,8 +197,9 @@ def test_config5_cloud_depth32(pkg, name):
     g = GOLDEN[name]
     a, la = gpu_render(pkg, g)
     check_against_golden(a, la, g, name)
-    b, lb = gpu_render(pkg, g, geom_path=4)
-    assert np.array_equal(a, b) and la == lb
+    for gp in (4, 6):
+        b, lb = gpu_render(pkg, g, geom_path=gp)
+        assert np.array_equal(a, b) and la == lb, gp
 
 
 def test_config5_cloud_1080p_properties(pkg):

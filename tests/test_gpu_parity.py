@@ -113,7 +113,7 @@ def test_cloud_256_primitives(pkg):
 
 
 @pytest.mark.parametrize("rotat", [0, 1])
-@pytest.mark.parametrize("geom_path", [1, 4, 5, 6])
+@pytest.mark.parametrize("geom_path", [1, 4, 5, 6, 7])
 def test_cloud_cull_is_conservative(pkg, rotat, geom_path):
     """Large primitive lists are culled (geom_path 1: per wave with padded bounding spheres; 4: per lane with a
     padded bounding-box hierarchy).  Culling may only skip primitives that cannot be hit, so a bigger sample of
@@ -210,7 +210,7 @@ def test_geometry_paths_identical(pkg):
     assert np.array_equal(a, d) and la == ld
 
 
-@pytest.mark.parametrize("geom_path", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("geom_path", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("scene,depth,rotat", [("sampleScene.txt", 6, 0), ("cornell_glass.txt", 10, 1),
                                                ("cloud256.txt", 5, 1)])
 def test_every_geometry_path_against_oracle(pkg, geom_path, scene, depth, rotat):
@@ -415,7 +415,7 @@ def test_random_scenes_bit_exact(pkg, seed):
     ma = (O.Material * len(mats))(*mats)
     cam = O.make_camera(W, H, eye, view, up, fovy)
     ref, live = O.render(ga, len(geoms), ma, len(mats), cam, depth, iters=iters, rr_start=3, seed=seed)
-    for geom_path in (1, 3, 4, 5, 6) if n_prims <= 32 else (1, 2, 4, 5, 6):
+    for geom_path in (1, 3, 4, 5, 6, 7) if n_prims <= 32 else (1, 2, 4, 5, 6, 7):
         with pkg.Renderer(0) as r:
             r.set_options(depth=depth, rr_start=3, seed=seed, geom_path=geom_path)
             r.set_scene(C.cast(ga, C.POINTER(pkg.StaticGeom)), len(geoms), C.cast(ma, C.POINTER(pkg.Material)), len(mats))
@@ -502,7 +502,7 @@ def test_direct_lighting_matches_oracle(pkg, scene, rotat, depth, iters):
     assert int(st0.shadow_rays) == 0 and not np.array_equal(plain, gpu)
 
 
-@pytest.mark.parametrize("geom_path", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("geom_path", [1, 2, 3, 4, 5, 6, 7])
 def test_direct_lighting_on_every_geometry_path(pkg, geom_path):
     W, H, depth = 80, 60, 4
     cpu, lc, shadows = cpu_render_dl("sampleScene_spec.txt", W, H, depth, iters=2, rotat=1)
@@ -663,7 +663,7 @@ def test_gpu_image_hashes_to_the_committed_golden(pkg, name):
 
 
 # ---------------------------------------------------------------- depth of field
-@pytest.mark.parametrize("geom_path,extra", [(0, {}), (3, {}), (4, {}), (6, {}), (5, {"direct_light": 1}),
+@pytest.mark.parametrize("geom_path,extra", [(0, {}), (3, {}), (4, {}), (6, {}), (7, {}), (7, {"direct_light": 1}), (5, {"direct_light": 1}),
                                              (0, {"strip_rows": 4, "strip_world": 2, "strip_rank": 1})])
 def test_thin_lens_camera_matches_oracle(pkg, geom_path, extra):
     """pt_options.lens_radius / focal_distance: camera rays start on the lens disc, so the camera kernel gives up its
