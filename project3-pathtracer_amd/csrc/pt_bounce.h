@@ -465,12 +465,7 @@ __device__ __forceinline__ void pairBatch(const KParams &p, const PR *s_prims, c
 }
 
 // Must be entered by all 64 lanes of the wave (lanes without a ray pass valid = false).
-// GROUPS: the pre-test reads the primitives' padded world boxes four at a time from 4-wide records (the batched walk's
-// node format, ptd::W4_FLOATS floats, KParams::pgroups): near / far planes of four primitives per ds_read_b128, picked
-// by address from the ray's direction signs -- 6 fma + max3 + min3 per box instead of 6 fma + 6 min/max + 4 merges.
-// Lanes of one sign octant read the same addresses, so the reads are broadcasts with at most 2 distinct rows per axis.
-// (!GROUPS: one box per primitive from s_boxes, relative to the shared eye for camera rays.)
-template <bool FIRST, bool GROUPS, class PR>
+template <bool FIRST, class PR>
 __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_prims, const float4 *s_boxes, const PairQueue q,
                                                f3 o, f3 d, bool valid, uint32_t lane)
 {
@@ -483,48 +478,6 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
     // slab distances as fma(plane, 1/d, -o/d): one instruction per plane; against (plane - o)/d this moves a plane by
     // less than 1.2e-6 |o|, far inside the boxes' padding
     const f3 oinv = FIRST ? mk(0, 0, 0) : mk(-(o.x * dinv.x), -(o.y * dinv.y), -(o.z * dinv.z));
-    if (GROUPS) {
-        static_assert(!(FIRST && GROUPS), "camera rays use the eye-relative boxes");
-        // per-lane byte offsets of the near / far planes inside a record: the hi half (16) on axes the ray runs down
-        const uint32_t sx = (__float_as_uint(dinv.x) >> 31) << 4, sy = (__float_as_uint(dinv.y) >> 31) << 4,
-                       sz = (__float_as_uint(dinv.z) >> 31) << 4;
-        const unsigned char *rec = reinterpret_cast<const unsigned char *>(s_boxes);
-        const unsigned char *nxp = rec + sx, *fxp = rec + (sx ^ 16u), *nyp = rec + 32 + sy, *fyp = rec + 32 + (sy ^ 16u),
-                            *nzp = rec + 64 + sz, *fzp = rec + 64 + (sz ^ 16u);
-        for (int grp = 0; grp < p.npgroups; ++grp) {
-            const int ro = grp * (W4_FLOATS * 4);
-            const float4 nx = *reinterpret_cast<const float4 *>(nxp + ro), fx = *reinterpret_cast<const float4 *>(fxp + ro);
-            const float4 ny = *reinterpret_cast<const float4 *>(nyp + ro), fy = *reinterpret_cast<const float4 *>(fyp + ro);
-            const float4 nz = *reinterpret_cast<const float4 *>(nzp + ro), fz = *reinterpret_cast<const float4 *>(fzp + ro);
-            const float nxa[4] = {nx.x, nx.y, nx.z, nx.w}, fxa[4] = {fx.x, fx.y, fx.z, fx.w};
-            const float nya[4] = {ny.x, ny.y, ny.z, ny.w}, fya[4] = {fy.x, fy.y, fy.z, fy.w};
-            const float nza[4] = {nz.x, nz.y, nz.z, nz.w}, fza[4] = {fz.x, fz.y, fz.z, fz.w};
-            const_u32_ptr cw = (const_u32_ptr)(uintptr_t)(p.pgroups + grp * W4_FLOATS + 24);      // child words: wave-uniform
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const uint32_t word = cw[c];
-                if ((word >> 31) == 0u) continue;                // empty slot / MESH: never has geometry
-                const float tn = fmaxf(fmaxf(__builtin_fmaf(nxa[c], dinv.x, oinv.x), __builtin_fmaf(nya[c], dinv.y, oinv.y)),
-                                       fmaxf(__builtin_fmaf(nza[c], dinv.z, oinv.z), 0.0f));
-                const float tf = fminf(fminf(__builtin_fmaf(fxa[c], dinv.x, oinv.x), __builtin_fmaf(fya[c], dinv.y, oinv.y)),
-                                       __builtin_fmaf(fza[c], dinv.z, oinv.z));
-                const uint64_t mask = __builtin_amdgcn_fcmpf(tn, tf, FCMP_OLE) & vmask;
-                if (mask == 0ull) continue;
-                const bool pass = __builtin_amdgcn_inverse_ballot_w64(mask);
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                const uint32_t g = (word >> 6) & 0xFFFFFFu;
-                if ((word & 0x40000000u) == 0u) {                // wave-uniform: sphere
-                    if (pass) q.q[0][(tail[0] + rank) & (QCAP - 1u)] = lane | (g << 8);
-                    tail[0] += (uint32_t)__popcll(mask);
-                    if (tail[0] - head[0] >= 64u) { pairBatch<0u, FIRST>(p, s_prims, q, head[0], 64u, lane); head[0] += 64u; }
-                } else {
-                    if (pass) q.q[1][(tail[1] + rank) & (QCAP - 1u)] = lane | (g << 8);
-                    tail[1] += (uint32_t)__popcll(mask);
-                    if (tail[1] - head[1] >= 64u) { pairBatch<1u, FIRST>(p, s_prims, q, head[1], 64u, lane); head[1] += 64u; }
-                }
-            }
-        }
-    } else
     for (int g = 0; g < p.nG; ++g) {
         const_u32_ptr hp = (const_u32_ptr)(uintptr_t)(p.prims + g);
         const uint32_t type = hp[0];
@@ -928,7 +881,7 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
 
 // nearest hit of (o, d) for the lanes with want == true, by the GEOM path.  Every lane of the wave must make the call
 // (the hit queue uses all 64 lanes as workers whatever their own ray).
-template <int GEOM, bool FIRST, bool GROUPS = false>
+template <int GEOM, bool FIRST>
 __device__ __forceinline__ Hit nearestHit(const KParams &p, const PrimPad *s_prims, const float4 *s_nodes, const WaveQueue &wq,
                                           f3 o, f3 d, bool want, uint32_t lane)
 {
@@ -951,7 +904,7 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const PrimPad *s_pri
             return nearestHitWalk4<FIRST>(p, p.prims, w4, pq, o, d, want, lane);
         }
         if (GEOM == GEOM_WALK_PAIR) return nearestHitWalkPairs<FIRST>(p, p.prims, s_nodes, pq, o, d, want, lane);
-        return nearestHitPairs<FIRST, GROUPS>(p, s_prims, s_nodes, pq, o, d, want, lane);
+        return nearestHitPairs<FIRST>(p, s_prims, s_nodes, pq, o, d, want, lane);
     }
     Hit h;
     h.any = false;
@@ -988,9 +941,6 @@ template <int WG, bool FIRST, int GEOM, int COMPACT, bool NEE = false>
 __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(const KParams p, const int bounce)
 {
     constexpr int NW = WG / 64;
-    // later bounces of the pair queue pre-test four primitives' boxes per LDS record (nearestHitPairs GROUPS); the camera
-    // kernel keeps one eye-relative box per primitive (its waves skip whole primitives)
-    constexpr bool PAIR_GROUPS = (GEOM == GEOM_PAIR) && !FIRST;
     constexpr bool PRIMS_IN_LDS = (GEOM == GEOM_LDS || GEOM == GEOM_QUEUE || GEOM == GEOM_PAIR);   // GEOM_BVH gathers records from global memory (L1/L2)
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     // LDS carve: [prims nG*128 B (GEOM 1,2)] [per-wave hit queues (GEOM 2)] [material planes] [scan scratch]
@@ -1000,8 +950,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
     // pair queue: the same region holds the primitives' padded boxes (2 float4 each; relative to the eye for camera rays)
     const int node_bytes = (GEOM == GEOM_BVH || GEOM == GEOM_WALK_PAIR) ? p.nnodes * (int)sizeof(BvhNode)
                            : (GEOM == GEOM_WALK4 ? (PT_W4_GLOBAL ? 0 : ((p.nnodes4 * W4_FLOATS * 4 + 127) & ~127))
-                                                 : (GEOM == GEOM_PAIR ? (PAIR_GROUPS ? ((p.npgroups * W4_FLOATS * 4 + 127) & ~127)
-                                                                                     : p.nG * 32 * (NEE ? 2 : 1)) : 0));
+                                                 : (GEOM == GEOM_PAIR ? p.nG * 32 * (NEE ? 2 : 1) : 0));
     unsigned char *s_queue = smem + prim_bytes + node_bytes;
     constexpr int WAVE_LDS = (GEOM == GEOM_QUEUE) ? (int)WAVE_QUEUE_BYTES
                              : ((GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR) ? (int)PAIR_QUEUE_BYTES
@@ -1031,11 +980,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
         const uint4 *fsrc = reinterpret_cast<const uint4 *>(p.face_n);
         for (int k = tid; k < p.nG * 8; k += WG) dst[p.nG * 9 + (k >> 3) * 9 + (k & 7)] = fsrc[k];
     }
-    if (PAIR_GROUPS) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(p.pgroups);
-        uint4 *dst = reinterpret_cast<uint4 *>(smem + prim_bytes);
-        for (int k = tid; k < p.npgroups * (W4_FLOATS / 4); k += WG) dst[k] = src[k];
-    } else if (GEOM == GEOM_PAIR) {
+    if (GEOM == GEOM_PAIR) {
         const uint4 *src = reinterpret_cast<const uint4 *>((FIRST && !(p.lens_radius > 0.0f)) ? p.box_eye : p.box_world);
         uint4 *dst = reinterpret_cast<uint4 *>(smem + prim_bytes);
         for (int k = tid; k < p.nG * 2; k += WG) dst[k] = src[k];
@@ -1192,8 +1137,8 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
         bool alive = false;
         const unsigned long long c1 = DEBUG_PHASE ? __builtin_amdgcn_s_memtime() : 0ull;
         // camera rays share the eye (host-side eye transforms and eye-relative boxes) unless a lens spreads their origins
-        const Hit h = (FIRST && p.lens_radius > 0.0f) ? nearestHit<GEOM, false, PAIR_GROUPS>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane)
-                                                      : nearestHit<GEOM, FIRST, PAIR_GROUPS>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane);
+        const Hit h = (FIRST && p.lens_radius > 0.0f) ? nearestHit<GEOM, false>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane)
+                                                      : nearestHit<GEOM, FIRST>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane);
         const unsigned long long c2 = DEBUG_PHASE ? __builtin_amdgcn_s_memtime() : 0ull;
         f3 L = mk(0, 0, 0);               // radiance this vertex adds to the path's sample
         // direct lighting: the shadow ray this lane wants traced and what it is worth if the light is visible
@@ -1328,8 +1273,8 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
             const uint64_t wmask = __ballot(want_shadow);
             if (wmask != 0ull) {                              // wave-uniform
                 shadow_count += (uint32_t)__popcll(wmask);
-                const Hit hs = nearestHit<GEOM, false, PAIR_GROUPS>(p, s_prims, (GEOM == GEOM_PAIR && !PAIR_GROUPS) ? s_nodes + 2 * p.nG : s_nodes,
-                                                                    wq, so, sd, want_shadow, (uint32_t)lane);
+                const Hit hs = nearestHit<GEOM, false>(p, s_prims, (GEOM == GEOM_PAIR) ? s_nodes + 2 * p.nG : s_nodes, wq, so, sd,
+                                                       want_shadow, (uint32_t)lane);
                 if (want_shadow && hs.any && hs.prim == lprim) {
                     const float tol = 1e-3f * ((ldist > 1.0f) ? ldist : 1.0f);
                     if (fabsf(hs.t - ldist) <= tol) L = L + Ld;          // the sampled point itself is what the ray reached

@@ -78,7 +78,6 @@ struct pt_ctx {
     int *d_lights = nullptr;    // direct lighting: indices of the emissive primitives
     ptd::BvhNode *d_bvh = nullptr;
     float *d_bvh4 = nullptr;    // 4-wide hierarchy (geom_path 7)
-    float *d_pgroups = nullptr; // every primitive's world box, four per 4-wide record (pair queue pre-test)
     float *d_image_own = nullptr;
     float *d_image_bound = nullptr;
     size_t image_bytes = 0, image_cap = 0;
@@ -494,29 +493,6 @@ int configure(pt_ctx *c)
                 be[8 * i + 4 + (size_t)a] = (float)(hi + pad);
             }
         }
-        {
-            // the same world boxes four primitives to a record (ptd::W4_FLOATS floats, the batched walk's node format):
-            // floats [8a, 8a+4) lo planes on axis a, [8a+4, 8a+8) hi planes, dwords 24..27 child words
-            const size_t ng = (c->geoms.size() + 3) / 4;
-            std::vector<float> grp((ng ? ng : 1) * ptd::W4_FLOATS, 0.0f);
-            for (size_t r = 0; r < ng; ++r)
-                for (int cc = 0; cc < 4; ++cc) {
-                    const size_t i = r * 4 + (size_t)cc;
-                    float *rec = grp.data() + r * ptd::W4_FLOATS;
-                    uint32_t word = 0u;
-                    for (int a = 0; a < 3; ++a) { rec[8 * a + cc] = 3e38f; rec[8 * a + 4 + cc] = -3e38f; }
-                    if (i < c->geoms.size() && c->geoms[i].type != PT_MESH) {
-                        for (int a = 0; a < 3; ++a) { rec[8 * a + cc] = bw[8 * i + (size_t)a]; rec[8 * a + 4 + cc] = bw[8 * i + 4 + (size_t)a]; }
-                        word = 0x80000000u | (c->geoms[i].type == PT_CUBE ? 0x40000000u : 0u) | ((uint32_t)i << 6);
-                    }
-                    memcpy(&rec[24 + cc], &word, 4);
-                }
-            if (c->d_pgroups) { (void)hipFree(c->d_pgroups); c->d_pgroups = nullptr; }
-            HIP_TRY(hipMalloc((void **)&c->d_pgroups, grp.size() * sizeof(float)));
-            HIP_TRY(hipMemcpy(c->d_pgroups, grp.data(), grp.size() * sizeof(float), hipMemcpyHostToDevice));
-            k.pgroups = c->d_pgroups;
-            k.npgroups = (int)ng;
-        }
         if (c->d_box_eye) { (void)hipFree(c->d_box_eye); c->d_box_eye = nullptr; }
         HIP_TRY(hipMalloc((void **)&c->d_box_eye, be.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(c->d_box_eye, be.data(), be.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -852,7 +828,6 @@ void pt_destroy(pt_ctx *c)
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_bvh) (void)hipFree(c->d_bvh);
     if (c->d_bvh4) (void)hipFree(c->d_bvh4);
-    if (c->d_pgroups) (void)hipFree(c->d_pgroups);
     if (c->d_image_own) (void)hipFree(c->d_image_own);
     if (c->d_pool) (void)hipFree(c->d_pool);
     if (c->d_lbuf) (void)hipFree(c->d_lbuf);

@@ -65,8 +65,6 @@ struct KParams {
     const float *bvh4;     // the same hierarchy collapsed to 4-wide nodes (GEOM_WALK4), ptd::W4_FLOATS floats per node
     int nnodes4;
     int wdepth;            // its depth in nodes (bounds the traversal stack)
-    const float *pgroups;  // all primitives' padded world boxes in 4-wide records, four primitives each in list order (pair queue pre-test)
-    int npgroups;
     int nbig;              // primitives too large to cull (walls...): tested by every ray before the walk
     int big[16];           // their indices
     const float *face_n;   // per primitive: 8 float4, entry `face code` = world normal of that box face (boxNormal's result)

@@ -224,9 +224,7 @@ size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg)
                                                       : (cfg.geom == GEOM_WALK4 ? PAIR_QUEUE_BYTES + WALK4_EXTRA_BYTES : 0)));
     if (cfg.geom == GEOM_WALK4 && !PT_W4_GLOBAL) prim += ((size_t)p.nnodes4 * W4_FLOATS * 4 + 127) & ~(size_t)127;
     if (cfg.geom == GEOM_BVH || cfg.geom == GEOM_WALK_PAIR) prim += (size_t)p.nnodes * sizeof(BvhNode);
-    // pair queue: one box per primitive (x2 with direct lighting) in the camera kernel, 4-wide records in the others;
-    // one figure for both kernels of a launch sequence
-    if (cfg.geom == GEOM_PAIR) prim += std::max((size_t)p.nG * 32 * (cfg.nee ? 2 : 1), ((size_t)p.npgroups * W4_FLOATS * 4 + 127) & ~(size_t)127);
+    if (cfg.geom == GEOM_PAIR) prim += (size_t)p.nG * 32 * (cfg.nee ? 2 : 1);
     size_t mats = (size_t)((p.nM * M_PLANES + 3) & ~3) * sizeof(float);
     size_t scan = (size_t)((2 * (cfg.workgroup / 64) + 2 + 3) & ~3) * sizeof(uint32_t);
     static const size_t extra = getenv("PT_EXTRA_LDS") ? (size_t)atol(getenv("PT_EXTRA_LDS")) : 0;   // occupancy experiments
