@@ -171,10 +171,7 @@ def main():
     # weak scaling: the frame grows with the GPU count at fixed aspect and camera (N=4 is BASELINE configs[3]'s
     # 3840x2160), so every rank owns a band of ~1920*1080 pixels of the same picture
     from project3_pathtracer_amd import sharding
-    if args.scaling == "strong" or world == 1:
-        W, Hfull = args.width, args.height           # the config's own frame, cut into `world` tiles
-    else:
-        W, Hfull = sharding.weak_scaled_frame(args.width, args.height, world)
+    W, Hfull = sharding.scaled_frame(args.width, args.height, world, args.scaling)
     sc.set_resolution(W, Hfull)
     # N>1: interleaved 8-row strips (strip k -> rank k % N) so that every rank sees the same mix of ceiling, walls
     # and floor; --bands switches to one contiguous band per rank (up to ~9 % slower at N=8: the bands differ in

@@ -107,7 +107,10 @@ typedef struct pt_options {
     int strip_world;      /*   rows, strip k belongs to context k % strip_world, and this context (strip_rank) renders its */
     int strip_rank;       /*   strips packed in order (balances ranks when path lengths vary down the frame); row_begin =
                                row_end = 0 then.  pt_strip_local_rows / pt_strip_global_row give the mapping.  0 = off */
-    int reserved[1];
+    int scatter;          /* 1 = subsurface random walk inside SCATTER materials that are not mirrors (calculateScatterAndAbsorption,
+                             ref stub src/interactions.h:36-39): free flight -ln(1-u)/RSCTCOEFF, isotropic re-direction
+                             (getRandomDirectionInSphere), Beer-Lambert with ABSCOEFF along every segment inside; the surface is
+                             a dielectric when REFR is set, index-matched otherwise; 0 = off (default) */
     float lens_radius;    /* > 0: thin-lens camera (depth of field): rays start on a disc of this radius around the eye and */
     float focal_distance; /*   aim at the pinhole ray's point on the plane focal_distance along the view axis; 0 = pinhole */
 } pt_options;
@@ -198,7 +201,10 @@ enum {
     PT_KAT_REFRACT = 12,        /* in: normal[3], incident[3], n1, n2            out: dir[3] (0 on TIR)    ref src/interactions.h:42-44 */
     PT_KAT_FRESNEL = 13,        /* in: normal[3], incident[3], n1, n2, trans[3]  out: reflectance          ref src/interactions.h:53-59 */
     PT_KAT_TRANSMISSION = 14,   /* in: absorption[3], distance                   out: rgb transmittance    ref src/interactions.h:31-33 */
-    PT_KAT_SAMPLE_LIGHT = 15    /* in: type (bits), transform[16], seed          out: p[3], n[3]           direct lighting sampler */
+    PT_KAT_SAMPLE_LIGHT = 15,   /* in: type (bits), transform[16], seed          out: p[3], n[3]           direct lighting sampler */
+    PT_KAT_LOG = 16,            /* in: x                                         out: ln(x)                deterministic log of the free-flight sampler */
+    PT_KAT_SCATTER = 17         /* in: o[3], d[3], depth, absorption[3], rsct, T[3], u1, u2, u3
+                                   out: scattered (0/1), o[3], d[3], depth, T[3]                           ref src/interactions.h:36-39 */
 };
 int  pt_device_kat(pt_ctx *ctx, int op, const float *in, int n_in, float *out, int n_out);
 

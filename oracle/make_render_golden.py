@@ -25,6 +25,7 @@ CASES = [
     ("direct_light", "sampleScene.txt", 1, 80, 60, 4, 2, {"direct_light": 1}),
     ("cloud256", "cloud256.txt", 1, 64, 36, 6, 1, {"seed": 5}),
     ("thin_lens", "sampleScene_spec.txt", 1, 72, 54, 5, 2, {"lens_radius": 0.3, "focal_distance": 11.0}),
+    ("subsurface", "sss_blobs.txt", 1, 72, 72, 10, 2, {"scatter": 1}),
 ]
 
 

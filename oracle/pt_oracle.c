@@ -389,6 +389,63 @@ o_vec3 o_calculateTransmission(o_vec3 absorptionCoefficient, float distance)
               o_exp_poly(-absorptionCoefficient.z * distance));
 }
 
+/* spec: deterministic natural logarithm of a positive normal fp32 from integer exponent extraction and fp32 + - * only
+ * (cephes logf: mantissa folded to [sqrt(1/2), sqrt(2)), degree-9 polynomial, Cody-Waite ln 2), so the HIP kernels and
+ * this oracle agree bit for bit; relative error < 2e-7.  x <= 0 (only 1 - u01 == 0 reaches it) -> -inf. */
+float o_log_poly(float x)
+{
+    union { float f; unsigned u; } b;
+    b.f = x;
+    if (!(x > 0.0f)) { b.u = 0xFF800000u; return b.f; }
+    int e = (int)((b.u >> 23) & 0xFFu) - 126;
+    b.u = (b.u & 0x807FFFFFu) | 0x3F000000u;              /* mantissa in [0.5, 1) */
+    float m = b.f;
+    if (m < 0.707106781186547524f) { e -= 1; m = (m + m) - 1.0f; }
+    else m = m - 1.0f;
+    float z = m * m;
+    float y = ((((((((7.0376836292e-2f * m - 1.1514610310e-1f) * m + 1.1676998740e-1f) * m - 1.2420140846e-1f) * m
+                   + 1.4249322787e-1f) * m - 1.6668057665e-1f) * m + 2.0000714765e-1f) * m - 2.4999993993e-1f) * m
+               + 3.3333331174e-1f) * m * z;
+    float fe = (float)e;
+    y = y + -2.12194440e-4f * fe;
+    y = y + -0.5f * z;
+    z = m + y;
+    return z + 0.693359375f * fe;
+}
+
+/* spec (ref stub: src/interactions.h:36-39, fields src/sceneStructs.h:63-74, README.md:179-184): one step of the random
+ * walk inside a scattering medium.  `r` starts inside the medium and would reach its boundary after *depth (world
+ * distance of the nearest hit).  Free flight s = -ln(1 - u)/sigma_s' with the REDUCED scattering coefficient; s < *depth:
+ * the path scatters at r.origin + s*r.direction into a uniformly random direction (getRandomDirectionInSphere of the two
+ * other draws), Beer-Lambert absorption over s -- returns 1 with r, *depth = s updated; otherwise Beer-Lambert over
+ * the whole segment, returns 0 and the caller handles the boundary.  `m` is the medium's material (unused beyond the
+ * properties, as in the reference's signature). */
+int o_calculateScatterAndAbsorption(o_ray *r, float *depth, const o_AbsorptionAndScatteringProperties *cur,
+                                    o_vec3 *unabsorbedColor, const o_material *m, float randomFloatForScatteringDistance,
+                                    float randomFloat2, float randomFloat3)
+{
+    (void)m;
+    const float sigma = cur->reducedScatteringCoefficient;
+    int scattered = 0;
+    float s = 0.0f;
+    if (sigma > 0.0f) {
+        const float a = 1.0f - randomFloatForScatteringDistance;
+        if (a > 0.0f) {
+            s = -o_log_poly(a) / sigma;
+            scattered = s < *depth;
+        }
+    }
+    if (scattered) {
+        *unabsorbedColor = mul3(*unabsorbedColor, o_calculateTransmission(cur->absorptionCoefficient, s));
+        r->origin = add3(r->origin, scale3(s, r->direction));
+        r->direction = o_getRandomDirectionInSphere(randomFloat2, randomFloat3, O_TRIG_POLY);
+        *depth = s;
+        return 1;
+    }
+    *unabsorbedColor = mul3(*unabsorbedColor, o_calculateTransmission(cur->absorptionCoefficient, *depth));
+    return 0;
+}
+
 /* spec (ref stub: src/interactions.h:47-50): mirror law d - 2(d.n)n */
 o_vec3 o_calculateReflectionDirection(o_vec3 normal, o_vec3 incident)
 {
@@ -622,7 +679,10 @@ static o_vec3 trace_path(const o_staticGeom *geoms, int nG, const o_material *ma
         o_minstd_seed(&rng, o_stream_seed(pixel, iteration, (unsigned)b + 1u, opt->seed));
         float u_select = o_u01(&rng), xi1 = o_u01(&rng), xi2 = o_u01(&rng), u_rr = o_u01(&rng);
 
-        const int diffuse = !(m->hasRefractive > 0.0f) && !(m->hasReflective > 0.0f);
+        /* spec (optional, opt->scatter): a SCATTER material that is not a mirror encloses a participating
+         * medium; its surface is a dielectric when REFR is set and index-matched (rays pass straight through) otherwise */
+        const int medium = opt->scatter && m->hasScatter > 0.0f && !(m->hasReflective > 0.0f);
+        const int diffuse = !(m->hasRefractive > 0.0f) && !(m->hasReflective > 0.0f) && !medium;
         if (nee && diffuse) {
             /* spec (ref samplers src/intersections.h:133-182): one light by u_light, one point on
              * it by the reference's float-seeded sampler, one shadow ray; estimator
@@ -659,12 +719,35 @@ static o_vec3 trace_path(const o_staticGeom *geoms, int nG, const o_material *ma
 
         /* spec (optional): a segment that ends on the inner side of a refractive surface ran through
          * the medium: Beer-Lambert with the material's ABSCOEFF over the segment's world length */
-        if (opt->absorption && m->hasRefractive > 0.0f && dot3(n, r.direction) > 0.0f &&
+        if (opt->absorption && !medium && m->hasRefractive > 0.0f && dot3(n, r.direction) > 0.0f &&
             (m->absorptionCoefficient.x != 0.0f || m->absorptionCoefficient.y != 0.0f || m->absorptionCoefficient.z != 0.0f))
             T = mul3(T, o_calculateTransmission(m->absorptionCoefficient, t_hit));
 
         const o_vec3 d_in = r.direction;
-        int lobe = o_calculateBSDF(&r, p, n, &T, m, u_select, xi1, xi2, opt->trig_mode);
+        int lobe;
+        int scattered = 0, pass_through = 0;
+        if (medium) {
+            const int inside = dot3(n, d_in) > 0.0f;
+            if (inside) {
+                /* the segment ran through the medium: three more draws of the bounce's stream decide whether the path
+                 * scatters before the boundary (isotropic, absorbed over the free flight) or reaches it (absorbed over
+                 * the whole segment) */
+                float u_sd = o_u01(&rng), u_s2 = o_u01(&rng), u_s3 = o_u01(&rng);
+                o_AbsorptionAndScatteringProperties props;
+                props.absorptionCoefficient = m->absorptionCoefficient;
+                props.reducedScatteringCoefficient = m->reducedScatterCoefficient;
+                float seg = t_hit;
+                scattered = o_calculateScatterAndAbsorption(&r, &seg, &props, &T, m, u_sd, u_s2, u_s3);
+            }
+            if (!scattered && !(m->hasRefractive > 0.0f)) {
+                /* index-matched boundary: the ray goes straight on; entering picks up the surface colour once */
+                if (!inside) T = mul3(T, m->color);
+                pass_through = 1;
+            }
+        }
+        if (scattered) lobe = 3;
+        else if (pass_through) lobe = 2;
+        else lobe = o_calculateBSDF(&r, p, n, &T, m, u_select, xi1, xi2, opt->trig_mode);
         if (lobe == 2) {
             /* spec: a transmitted ray must start on the far side of the surface, but `p` was pulled back towards
              * the ray origin by getPointOnRay's 1e-4 object-space epsilon (ref: src/intersections.h:46-48), which

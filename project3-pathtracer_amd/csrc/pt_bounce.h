@@ -1174,7 +1174,9 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
                     const f3 nf = backside ? -h.n : h.n;
                     const float refr = s_mats[M_REFR * p.nM + m];
                     const float refl = s_mats[M_REFL * p.nM + m];
-                    const bool diffuse = !(refr > 0.0f) && !(refl > 0.0f);
+                    // subsurface scattering (pt_options.scatter): a SCATTER material that is not a mirror encloses a medium
+                    const bool medium = p.scatter != 0 && s_mats[M_SCAT * p.nM + m] > 0.0f && !(refl > 0.0f);
+                    const bool diffuse = !(refr > 0.0f) && !(refl > 0.0f) && !medium;
                     if (NEE && diffuse) {
                         // one light, one point on it (the reference's float-seeded samplers), one shadow ray;
                         // estimator T*c/pi * Le * cos_x cos_y / d^2 * (area * number of lights)
@@ -1218,7 +1220,41 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
                     f3 nd;
                     f3 bias_n = nf;
                     float bias = 0.0002f;                 // RAY_BIAS_AMOUNT, ref: src/utilities.h:26
-                    if (refr > 0.0f) {
+                    bool scattered = false, pass_through = false;
+                    if (medium) {
+                        if (backside) {
+                            // the segment ran through the medium: three more draws of the bounce's stream decide whether
+                            // the path scatters before the boundary or reaches it (calculateScatterAndAbsorption)
+                            s = minstd_next(s);
+                            const float u_sd = u01_of(s);
+                            s = minstd_next(s);
+                            const float u_s2 = u01_of(s);
+                            s = minstd_next(s);
+                            const float u_s3 = u01_of(s);
+                            const f3 sa = mk(s_mats[M_AR * p.nM + m], s_mats[M_AG * p.nM + m], s_mats[M_AB * p.nM + m]);
+                            f3 mo = o, md = d;
+                            float seg = h.t;
+                            scattered = calculateScatterAndAbsorption(mo, md, seg, sa, s_mats[M_RSCT * p.nM + m], T, u_sd, u_s2, u_s3);
+                            if (scattered) { o = mo; nd = md; }
+                        }
+                        if (!scattered && !(refr > 0.0f)) {
+                            // index-matched boundary: the ray goes straight on; entering picks up the surface colour once
+                            if (!backside) T = T * mk(s_mats[M_CR * p.nM + m], s_mats[M_CG * p.nM + m], s_mats[M_CB * p.nM + m]);
+                            pass_through = true;
+                        }
+                    }
+                    if (scattered) {
+                        // the new ray starts inside the medium, where the walk left it
+                    } else if (pass_through) {
+                        nd = d;
+                        bias_n = -nf;
+                        const Prim *HP = PRIMS_IN_LDS ? &s_prims[h.prim] : &p.prims[h.prim];
+                        const float4 *iv = reinterpret_cast<const float4 *>(HP->inv);
+                        const float4 i0 = iv[0], i1 = iv[1], i2 = iv[2];
+                        const float inv[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
+                        const f3 v = mulMV(inv, d, 0.0f);
+                        bias = 0.0002f + 1e-4f * rsqrt_rn(dot(v, v));
+                    } else if (refr > 0.0f) {
                         const float ior = s_mats[M_IOR * p.nM + m];
                         const float n1 = backside ? ior : 1.0f;
                         const float n2 = backside ? 1.0f : ior;
@@ -1226,7 +1262,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
                         bool tir;
                         const f3 tdir = transmissionDirection(nf, d, n1, n2, tir);
                         const float Rf = fresnelReflectance(nf, d, n1, n2, tdir);
-                        if (p.absorption && backside) {
+                        if (p.absorption && backside && !medium) {
                             // the segment that ends on the inner side of the surface ran through the medium
                             const f3 sa = mk(s_mats[M_AR * p.nM + m], s_mats[M_AG * p.nM + m], s_mats[M_AB * p.nM + m]);
                             if (sa.x != 0.0f || sa.y != 0.0f || sa.z != 0.0f) T = T * calculateTransmission(sa, h.t);
@@ -1253,7 +1289,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
                         T = T * mk(s_mats[M_CR * p.nM + m], s_mats[M_CG * p.nM + m], s_mats[M_CB * p.nM + m]);
                         nd = randomDirectionInHemisphere(nf, xi1, xi2);
                     }
-                    o = h.p + bias * bias_n;
+                    if (!scattered) o = h.p + bias * bias_n;
                     d = nd;
                     alive = true;
                     if (p.rr_start >= 0 && bounce >= p.rr_start) {      // Russian roulette

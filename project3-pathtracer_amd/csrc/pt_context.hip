@@ -408,6 +408,7 @@ int configure(pt_ctx *c)
         }
         k.nlights = o.direct_light ? (int)lights.size() : 0;
         k.absorption = o.absorption ? 1 : 0;
+        k.scatter = o.scatter ? 1 : 0;
         if (c->d_lights) { (void)hipFree(c->d_lights); c->d_lights = nullptr; }
         HIP_TRY(hipMalloc((void **)&c->d_lights, (lights.size() ? lights.size() : 1) * sizeof(int)));
         if (!lights.empty()) HIP_TRY(hipMemcpy(c->d_lights, lights.data(), lights.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -511,6 +512,7 @@ int configure(pt_ctx *c)
             planes[ptd::M_IOR * nM + i] = m.indexOfRefraction; planes[ptd::M_EMIT * nM + i] = m.emittance;
             planes[ptd::M_AR * nM + i] = m.absorptionCoefficient.x; planes[ptd::M_AG * nM + i] = m.absorptionCoefficient.y;
             planes[ptd::M_AB * nM + i] = m.absorptionCoefficient.z;
+            planes[ptd::M_SCAT * nM + i] = m.hasScatter; planes[ptd::M_RSCT * nM + i] = m.reducedScatterCoefficient;
         }
         if (c->d_mats) { (void)hipFree(c->d_mats); c->d_mats = nullptr; }
         HIP_TRY(hipMalloc((void **)&c->d_mats, planes.size() * sizeof(float)));
@@ -853,6 +855,7 @@ int pt_set_options(pt_ctx *c, const pt_options *o)
     if (o->compaction < 0 || o->compaction > 2) return fail(PT_ERR_INVALID, "compaction %d not 0, 1 or 2", o->compaction);
     if (o->direct_light < 0 || o->direct_light > 1) return fail(PT_ERR_INVALID, "direct_light %d not 0 or 1", o->direct_light);
     if (o->absorption < 0 || o->absorption > 1) return fail(PT_ERR_INVALID, "absorption %d not 0 or 1", o->absorption);
+    if (o->scatter < 0 || o->scatter > 1) return fail(PT_ERR_INVALID, "scatter %d not 0 or 1", o->scatter);
     if (!(o->lens_radius >= 0.0f) || (o->lens_radius > 0.0f && !(o->focal_distance > 0.0f)))
         return fail(PT_ERR_INVALID, "lens radius %g / focal distance %g", (double)o->lens_radius, (double)o->focal_distance);
     if (o->direct_light && o->compaction != 1) return fail(PT_ERR_INVALID, "direct_light needs compaction 1 (got %d)", o->compaction);
@@ -1064,8 +1067,8 @@ int pt_device_kat(pt_ctx *c, int op, const float *in, int n_in, float *out, int 
 {
     if (!c || !in || !out || n_in < 1 || n_out < 1 || n_in > 4096 || n_out > 4096)
         return fail(PT_ERR_INVALID, "pt_device_kat: bad arguments");
-    static const int need_in[] = {0, 1, 1, 5, 39, 5, 16, 17, 17, 20, 7, 6, 8, 11, 4, 18};
-    if (op < 1 || op > 15 || n_in < need_in[op]) return fail(PT_ERR_INVALID, "pt_device_kat: op %d needs %d inputs", op, op >= 1 && op <= 15 ? need_in[op] : 0);
+    static const int need_in[] = {0, 1, 1, 5, 39, 5, 16, 17, 17, 20, 7, 6, 8, 11, 4, 18, 1, 17};
+    if (op < 1 || op > 17 || n_in < need_in[op]) return fail(PT_ERR_INVALID, "pt_device_kat: op %d needs %d inputs", op, op >= 1 && op <= 17 ? need_in[op] : 0);
     HIP_TRY(hipSetDevice(c->device));
     float *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, (size_t)(n_in + n_out) * sizeof(float)));

@@ -148,7 +148,7 @@ static_assert(sizeof(BvhNode) == 32, "BvhNode must be 32 B");
 static constexpr int W4_FLOATS = 28;
 
 // Material planes (SoA): plane k of material id at mats[k * nM + id]
-enum { M_CR = 0, M_CG, M_CB, M_SR, M_SG, M_SB, M_REFL, M_REFR, M_IOR, M_EMIT, M_AR, M_AG, M_AB, M_PLANES };
+enum { M_CR = 0, M_CG, M_CB, M_SR, M_SG, M_SB, M_REFL, M_REFR, M_IOR, M_EMIT, M_AR, M_AG, M_AB, M_SCAT, M_RSCT, M_PLANES };
 
 // ---------------------------------------------------------------------------------------------
 // RNG: Wang hash (ref: src/intersections.h:26-34) + thrust::minstd_rand + uniform_real_distribution<float>
@@ -480,6 +480,56 @@ __device__ __forceinline__ f3 calculateTransmission(f3 absorptionCoefficient, fl
 {
     return mk(exp_poly(-absorptionCoefficient.x * distance), exp_poly(-absorptionCoefficient.y * distance),
               exp_poly(-absorptionCoefficient.z * distance));
+}
+
+// deterministic natural log of a positive normal fp32 (same sequence as the oracle's o_log_poly: cephes logf with the
+// exponent taken from the bit pattern); x <= 0 -> -inf
+__device__ __forceinline__ float log_poly(float x)
+{
+    uint32_t b = __float_as_uint(x);
+    if (!(x > 0.0f)) return __uint_as_float(0xFF800000u);
+    int e = (int)((b >> 23) & 0xFFu) - 126;
+    float m = __uint_as_float((b & 0x807FFFFFu) | 0x3F000000u);
+    if (m < 0.707106781186547524f) { e -= 1; m = (m + m) - 1.0f; }
+    else m = m - 1.0f;
+    float z = m * m;
+    float y = ((((((((7.0376836292e-2f * m - 1.1514610310e-1f) * m + 1.1676998740e-1f) * m - 1.2420140846e-1f) * m
+                   + 1.4249322787e-1f) * m - 1.6668057665e-1f) * m + 2.0000714765e-1f) * m - 2.4999993993e-1f) * m
+               + 3.3333331174e-1f) * m * z;
+    const float fe = (float)e;
+    y = y + -2.12194440e-4f * fe;
+    y = y + -0.5f * z;
+    z = m + y;
+    return z + 0.693359375f * fe;
+}
+
+// calculateScatterAndAbsorption (stub ref: src/interactions.h:36-39): one step of the random walk inside a scattering
+// medium.  (o, d) starts inside and would reach the boundary after `depth`; free flight s = -ln(1 - u)/sigma_s'.
+// true: scattered at o + s*d into a uniformly random direction, throughput absorbed over s, depth = s;
+// false: boundary reached, throughput absorbed over the whole segment.
+__device__ __forceinline__ bool calculateScatterAndAbsorption(f3 &o, f3 &d, float &depth, f3 absorptionCoefficient,
+                                                              float reducedScatteringCoefficient, f3 &unabsorbedColor,
+                                                              float randomFloatForScatteringDistance, float randomFloat2,
+                                                              float randomFloat3)
+{
+    bool scattered = false;
+    float s = 0.0f;
+    if (reducedScatteringCoefficient > 0.0f) {
+        const float a = 1.0f - randomFloatForScatteringDistance;
+        if (a > 0.0f) {
+            s = -log_poly(a) / reducedScatteringCoefficient;
+            scattered = s < depth;
+        }
+    }
+    if (scattered) {
+        unabsorbedColor = unabsorbedColor * calculateTransmission(absorptionCoefficient, s);
+        o = o + s * d;
+        d = getRandomDirectionInSphere(randomFloat2, randomFloat3);
+        depth = s;
+        return true;
+    }
+    unabsorbedColor = unabsorbedColor * calculateTransmission(absorptionCoefficient, depth);
+    return false;
 }
 
 // getRandomPointOnCube with the five face-choice thresholds (side areas over the total) and the face normals taken from

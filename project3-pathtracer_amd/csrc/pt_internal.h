@@ -89,6 +89,7 @@ struct KParams {
     uint32_t w_magic;      // y = (global pixel * w_magic) >> w_shift, exact for every pixel index of the frame (< 2^29)
     uint32_t w_shift;
     int absorption;        // 1 = Beer-Lambert absorption inside refractive objects (material planes M_AR..M_AB)
+    int scatter;           // 1 = subsurface random walk inside SCATTER materials (material planes M_SCAT, M_RSCT)
     int nlights;           // direct lighting: emissive primitives (0 = feature off), indices in `lights`
     const int *lights;
 };

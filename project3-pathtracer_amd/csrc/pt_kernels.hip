@@ -105,6 +105,18 @@ __global__ void k_device_kat(int op, const float *in, float *out, int n_out)
         out[0] = y.x; out[1] = y.y; out[2] = y.z; out[3] = n.x; out[4] = n.y; out[5] = n.z;
         break;
     }
+    case PT_KAT_LOG: out[0] = log_poly(in[0]); break;
+    case PT_KAT_SCATTER: {
+        f3 o = mk(in[0], in[1], in[2]), d = mk(in[3], in[4], in[5]), T = mk(in[11], in[12], in[13]);
+        float depth = in[6];
+        const bool sc = calculateScatterAndAbsorption(o, d, depth, mk(in[7], in[8], in[9]), in[10], T, in[14], in[15], in[16]);
+        out[0] = sc ? 1.0f : 0.0f;
+        put3(1, o);
+        put3(4, d);
+        out[7] = depth;
+        put3(8, T);
+        break;
+    }
     default: break;
     }
 }

@@ -13,6 +13,7 @@
 //   PT_RR_START (-1)      first bounce with Russian roulette, -1 = off
 //   PT_DIRECT_LIGHT (0)   1 = sample the lights explicitly at diffuse vertices (getRandomPointOnCube / ...OnSphere)
 //   PT_ABSORPTION (0)     1 = Beer-Lambert absorption (ABSCOEFF) inside refractive objects (calculateTransmission)
+//   PT_SCATTER (0)        1 = subsurface random walk inside SCATTER materials (calculateScatterAndAbsorption)
 //   PT_LENS_RADIUS (0), PT_FOCAL_DISTANCE (1)   thin-lens camera (depth of field); radius 0 = pinhole
 //   PT_SEED (0)           RNG stream selector
 //   PT_DEVICES (0)        comma-separated HIP devices; with several, each renders a band of rows of the frame
@@ -119,6 +120,7 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
         o.rr_start = env_int("PT_RR_START", o.rr_start);
         o.direct_light = env_int("PT_DIRECT_LIGHT", o.direct_light);
         o.absorption = env_int("PT_ABSORPTION", o.absorption);
+        o.scatter = env_int("PT_SCATTER", o.scatter);
         if (getenv("PT_LENS_RADIUS")) o.lens_radius = (float)atof(getenv("PT_LENS_RADIUS"));
         if (getenv("PT_FOCAL_DISTANCE")) o.focal_distance = (float)atof(getenv("PT_FOCAL_DISTANCE"));
         o.seed = (unsigned)env_int("PT_SEED", 0);

@@ -71,6 +71,17 @@ def weak_scaled_frame(width, height, world):
     return int(round(width * s / 16.0)) * 16, int(round(height * s / 2.0)) * 2
 
 
+def scaled_frame(width, height, world, scaling="weak"):
+    """Frame rendered by `world` GPUs: "strong" = the configuration's own frame, cut into `world` tiles (BASELINE
+    configs[3] and [4] are quoted this way: one 3840x2160 / 1920x1080 frame over the 8 GPUs of a node); "weak" = a frame
+    that grows with the GPU count so that every rank keeps ~width x height pixels."""
+    if scaling not in ("weak", "strong"):
+        raise ValueError("scaling")
+    if scaling == "strong" or world == 1:
+        return width, height
+    return weak_scaled_frame(width, height, world)
+
+
 def gather_bands(local_band, height, world, rank, dist=None, dst=0):
     """Gather the per-rank bands (tensors [max_band_rows, W, 3], only the first rows of each are valid) to
     `dst` and assemble the [height, W, 3] frame there.  Returns the frame on dst, None elsewhere.

@@ -10,6 +10,8 @@ the other files are derived scenes the BASELINE configs call for:
   sampleScene_spec.txt  same, REFL 1 on materials 3/4/6 ("diffuse+specular")
   cornell_glass.txt     Cornell box with a glass sphere (REFR 1, REFRIOR 2.2), config 3
   cloud256.txt          256 random spheres/cubes + walls + light, config 5 (compaction stress)
+  sss_blobs.txt         Cornell box with two scattering media (SCATTER 1): an index-matched wax-like sphere and a
+                        scattering glass cube, for pt_options.scatter (calculateScatterAndAbsorption)
 
 Run: python scenes/make_scenes.py   (deterministic; outputs are committed)
 """
@@ -20,8 +22,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 MAT_KEYS = ["RGB", "SPECEX", "SPECRGB", "REFL", "REFR", "REFRIOR", "SCATTER", "ABSCOEFF", "RSCTCOEFF", "EMITTANCE"]
 
 
-def mat(rgb, specrgb=(1, 1, 1), refl=0, refr=0, ior=0, absc=(0, 0, 0), rsct=0, emit=0):
-    return dict(RGB=rgb, SPECEX=0, SPECRGB=specrgb, REFL=refl, REFR=refr, REFRIOR=ior, SCATTER=0, ABSCOEFF=absc,
+def mat(rgb, specrgb=(1, 1, 1), refl=0, refr=0, ior=0, absc=(0, 0, 0), rsct=0, emit=0, scatter=0):
+    return dict(RGB=rgb, SPECEX=0, SPECRGB=specrgb, REFL=refl, REFR=refr, REFRIOR=ior, SCATTER=scatter, ABSCOEFF=absc,
                 RSCTCOEFF=rsct, EMITTANCE=emit)
 
 
@@ -193,6 +195,18 @@ if __name__ == "__main__":
     anim_cam = [((0, 4.5, 12 - 1.5 * f), (0.05 * f, 0, -1), (0, 1, 0)) for f in range(3)]
     emit_animated("sampleScene_anim.txt", spec, anim_cam, dict(SAMPLE_CAMERA, res=(320, 240), iterations=8, file="anim.bmp"),
                   anim_objects)
+
+    sss_materials = list(SAMPLE_MATERIALS) + [
+        mat((.95, .85, .7), scatter=1, absc=(.05, .25, .6), rsct=3),                 # 9 wax: index-matched medium
+        mat((0, 0, 0), refr=1, ior=1.5, scatter=1, absc=(.4, .1, .05), rsct=1.5),    # 10 cloudy glass
+    ]
+    sss_objects = WALLS + [
+        ("sphere", 9, (-1.8, 2.2, 0.5), (0, 0, 0), (3.6, 3.6, 3.6)),
+        ("cube", 10, (2.2, 1.8, -0.5), (0, 25, 0), (2.6, 3.6, 2.6)),
+        ("sphere", 3, (0, 6.5, -2.5), (0, 0, 0), (2, 2, 2)),
+        LIGHT,
+    ]
+    emit("sss_blobs.txt", sss_materials, dict(SAMPLE_CAMERA, res=(800, 800), iterations=1000, file="sss.bmp"), sss_objects)
 
     cm, co = cloud()
     emit("cloud256.txt", cm, dict(SAMPLE_CAMERA, res=(1920, 1080), iterations=4096, file="cloud.bmp"), co)

@@ -31,6 +31,12 @@ def run(case, override):
         opts["direct_light"] = 1
     if rng.random() < 0.4:
         opts["absorption"] = 1
+    if rng.random() < 0.35:
+        opts["scatter"] = 1
+        mats[3].hasScatter, mats[3].reducedScatterCoefficient = 1.0, float(np.float32(rng.uniform(0.2, 6)))
+        if rng.random() < 0.5:
+            mats[1].hasScatter, mats[1].reducedScatterCoefficient = 1.0, float(np.float32(rng.uniform(0.2, 6)))
+            mats[1].absorptionCoefficient = O.v3(*rng.uniform(0, 2, 3))
     if rng.random() < 0.3:
         opts["lens_radius"] = float(np.float32(rng.uniform(0.05, 0.6)))
         opts["focal_distance"] = float(np.float32(rng.uniform(2, 12)))

@@ -61,7 +61,12 @@ class Fresnel(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("depth", C.c_int), ("rr_start", C.c_int), ("seed", C.c_uint), ("trig_mode", C.c_int),
-                ("direct_light", C.c_int), ("absorption", C.c_int), ("lens_radius", C.c_float), ("focal_distance", C.c_float)]
+                ("direct_light", C.c_int), ("absorption", C.c_int), ("lens_radius", C.c_float), ("focal_distance", C.c_float),
+                ("scatter", C.c_int)]
+
+
+class ScatterProps(C.Structure):       # AbsorptionAndScatteringProperties, ref: src/interactions.h:16-19
+    _fields_ = [("absorptionCoefficient", Vec3), ("reducedScatteringCoefficient", C.c_float)]
 
 
 class Scene(C.Structure):
@@ -126,6 +131,8 @@ def lib():
         "o_exp_poly": (f, [f]),
         "o_calculateTransmission": (Vec3, [Vec3, f]),
         "o_sampleLight": (None, [P(StaticGeom), f, P(Vec3), P(Vec3)]),
+        "o_log_poly": (f, [f]),
+        "o_calculateScatterAndAbsorption": (i, [P(Ray), P(f), P(ScatterProps), P(Vec3), P(Material), f, f, f]),
         "o_trace_path": (Vec3, [P(StaticGeom), i, P(Material), i, P(CameraData), P(Options), i, i, u, P(i)]),
         "o_buildTransformationMatrix": (Mat4, [Vec3, Vec3, Vec3, i, P(Mat4)]),
         "o_camera_fov": (Vec2, [f, Vec2]),
@@ -170,10 +177,12 @@ def make_geom(gtype, materialid, t, r, s, rotat_units=ROTAT_RADIANS):
     return g
 
 
-def make_material(color=(1, 1, 1), spec=(1, 1, 1), refl=0.0, refr=0.0, ior=0.0, emittance=0.0):
+def make_material(color=(1, 1, 1), spec=(1, 1, 1), refl=0.0, refr=0.0, ior=0.0, emittance=0.0, scatter=0.0,
+                  absorption=(0, 0, 0), rsct=0.0):
     m = Material()
     m.color, m.specularColor = v3(color), v3(spec)
     m.hasReflective, m.hasRefractive, m.indexOfRefraction, m.emittance = refl, refr, ior, emittance
+    m.hasScatter, m.absorptionCoefficient, m.reducedScatterCoefficient = scatter, v3(absorption), rsct
     return m
 
 
@@ -215,7 +224,8 @@ class LoadedScene:
 
 
 def render(geoms, nG, mats, nM, cam, depth, iters=1, iter_first=1, rr_start=-1, seed=0, trig=TRIG_POLY,
-           image=None, nthreads=None, direct_light=0, shadow_out=None, absorption=0, lens_radius=0.0, focal_distance=1.0):
+           image=None, nthreads=None, direct_light=0, shadow_out=None, absorption=0, lens_radius=0.0, focal_distance=1.0,
+           scatter=0):
     """Returns (image[H,W,3] float32, live_in[depth] uint64); shadow_out (a list) receives the shadow-ray count."""
     W, H = int(cam.resolution.x), int(cam.resolution.y)
     if image is None:
@@ -223,7 +233,7 @@ def render(geoms, nG, mats, nM, cam, depth, iters=1, iter_first=1, rr_start=-1, 
     else:
         image = np.ascontiguousarray(image, dtype=np.float32).copy()
     live = np.zeros(depth, dtype=np.uint64)
-    opt = Options(depth, rr_start, seed, trig, direct_light, absorption, lens_radius, focal_distance)
+    opt = Options(depth, rr_start, seed, trig, direct_light, absorption, lens_radius, focal_distance, scatter)
     if nthreads is None:
         nthreads = os.cpu_count() or 1
     shadow = C.c_ulonglong(0)

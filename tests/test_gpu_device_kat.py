@@ -165,3 +165,35 @@ def test_transmission_and_light_sampler_against_oracle(gpu):
         L.o_sampleLight(C.byref(g), float(k * 37), C.byref(p), C.byref(n))
         out = gpu.device_kat(SAMPLE_LIGHT, list(bits([kind])) + rows16(g.transform) + [float(k * 37)], 6)
         assert_bits(out, p.tup() + n.tup(), "sampleLight")
+
+
+LOG, SCATTER = 16, 17
+
+
+def test_log_and_scatter_step_against_oracle(gpu):
+    """The free-flight sampler's deterministic log and calculateScatterAndAbsorption on the device == the oracle."""
+    L = O.lib()
+    rng = np.random.default_rng(17)
+    xs = np.concatenate([rng.random(400), 2.0 ** -rng.uniform(0, 24, 100), [1.0, 0.5, 0.70710677, 0.70710683, 5.9604645e-08]]).astype(np.float32)
+    for x in xs:
+        assert_bits(gpu.device_kat(LOG, [float(x)], 1)[0], L.o_log_poly(float(x)), "log_poly")
+    assert gpu.device_kat(LOG, [0.0], 1)[0] == -np.inf
+    for k in range(300):
+        o = [float(np.float32(v)) for v in rng.uniform(-3, 3, 3)]
+        d = normalize32(rng.normal(size=3))
+        depth = float(np.float32(10 ** rng.uniform(-3, 1)))
+        sa = [float(np.float32(v)) for v in rng.uniform(0, 4, 3)]
+        rsct = float(np.float32(rng.choice([0.0, 0.5, 3.0, 13.0])))
+        T = [float(np.float32(v)) for v in rng.uniform(0, 1, 3)]
+        u = [float(np.float32(v)) for v in rng.random(3)]
+        if k % 50 == 0:
+            u[0] = 1.0
+        r = O.Ray(O.v3(o), O.v3(d))
+        dep = C.c_float(depth)
+        props = O.ScatterProps(O.v3(sa), rsct)
+        col = O.v3(T)
+        m = O.make_material()
+        sc = L.o_calculateScatterAndAbsorption(C.byref(r), C.byref(dep), C.byref(props), C.byref(col), C.byref(m), u[0], u[1], u[2])
+        out = gpu.device_kat(SCATTER, o + d + [depth] + sa + [rsct] + T + u, 11)
+        assert int(out[0]) == sc
+        assert_bits(out[1:11], r.origin.tup() + r.direction.tup() + (dep.value,) + col.tup(), "calculateScatterAndAbsorption")

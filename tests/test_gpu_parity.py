@@ -46,11 +46,11 @@ def gpu_render(pkg, scene, w, h, depth, iters=1, iter_first=1, image=None, rotat
     return img, [int(x) for x in st.live_in[:depth]], st
 
 
-def cpu_render(scene, w, h, depth, iters=1, iter_first=1, image=None, rotat=0, rr_start=-1, seed=0):
+def cpu_render(scene, w, h, depth, iters=1, iter_first=1, image=None, rotat=0, rr_start=-1, seed=0, **more):
     sc = O.LoadedScene(os.path.join(SCENES, scene), rotat)
     sc.set_resolution(w, h)
     img, live = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, depth, iters=iters,
-                         iter_first=iter_first, rr_start=rr_start, seed=seed, image=image)
+                         iter_first=iter_first, rr_start=rr_start, seed=seed, image=image, **more)
     return img, [int(x) for x in live]
 
 
@@ -642,6 +642,33 @@ def test_very_large_primitive_lists(pkg, n_prims, paths):
             img = r.download_image()
             st = r.stats()
         check(img, ref, [int(x) for x in st.live_in[:depth]], [int(x) for x in live], f"{n_prims} primitives geom_path={gp}")
+
+
+# ---------------------------------------------------------------- subsurface scattering
+@pytest.mark.parametrize("geom_path", [0, 1, 2, 3, 4, 5, 6, 7])
+def test_subsurface_scattering_matches_oracle(pkg, geom_path):
+    """pt_options.scatter: random walk inside the SCATTER media of sss_blobs.txt (an index-matched sphere, a scattering
+    glass cube): free flights, isotropic re-direction, absorption and the three extra draws per inside-segment follow
+    the oracle bit for bit on every geometry path."""
+    g, lg, _ = gpu_render(pkg, "sss_blobs.txt", 96, 96, 12, iters=3, rotat=1, scatter=1, geom_path=geom_path)
+    c, lc = cpu_render("sss_blobs.txt", 96, 96, 12, iters=3, rotat=1, scatter=1)
+    check(g, c, lg, lc, f"subsurface scattering geom_path={geom_path}")
+
+
+def test_subsurface_scattering_with_everything_else(pkg):
+    """... together with Russian roulette, absorption (refractive non-scatter materials only), direct lighting (media
+    are not diffuse vertices) and iteration batching."""
+    kw = dict(rr_start=2, absorption=1, direct_light=1)
+    g, lg, st = gpu_render(pkg, "sss_blobs.txt", 80, 60, 10, iters=5, rotat=1, scatter=1, batch=4, **kw)
+    sh = []
+    c, lc = cpu_render("sss_blobs.txt", 80, 60, 10, iters=5, rotat=1, scatter=1, shadow_out=sh, **kw)
+    check(g, c, lg, lc, "scatter + rr + absorption + direct light")
+    assert int(st.shadow_rays) == sh[0]
+    off, lo, _ = gpu_render(pkg, "sss_blobs.txt", 80, 60, 10, iters=5, rotat=1, batch=4, **kw)
+    assert not np.array_equal(off, g)
+    with pkg.Renderer(0) as r:
+        with pytest.raises(pkg.PtError):
+            r.set_options(scatter=2)
 
 
 # ---------------------------------------------------------------- committed golden fixtures

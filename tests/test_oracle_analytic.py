@@ -410,3 +410,72 @@ def test_thin_lens_focus():
     n_blur, e_blur = lit(lens_radius=0.4, focal_distance=5.0)
     assert abs(n_focus - n_pin) <= 0.35 * n_pin and n_blur > 2.5 * n_pin
     assert abs(e_focus - e_pin) <= 0.1 * e_pin and abs(e_blur - e_pin) <= 0.15 * e_pin
+
+
+# ------------------------------------------------------------------ subsurface scattering
+def test_log_poly_accuracy():
+    L = O.lib()
+    xs = np.concatenate([np.linspace(1e-7, 1.0, 5001), 2.0 ** -np.arange(1, 25), [0.70710677, 0.70710683]]).astype(np.float32)
+    for x in xs:
+        got = L.o_log_poly(float(x))
+        want = math.log(float(x))
+        assert abs(got - want) <= 2e-7 * max(1.0, abs(want)), (float(x), got, want)
+    assert L.o_log_poly(1.0) == 0.0 and L.o_log_poly(0.0) == -math.inf
+
+
+def _scatter(o, d, depth, sa, rsct, T, u1, u2, u3):
+    L = O.lib()
+    r = O.Ray(O.v3(o), O.v3(d))
+    dep = C.c_float(depth)
+    props = O.ScatterProps(O.v3(sa), rsct)
+    col = O.v3(T)
+    m = O.make_material()
+    sc = L.o_calculateScatterAndAbsorption(C.byref(r), C.byref(dep), C.byref(props), C.byref(col), C.byref(m), u1, u2, u3)
+    return sc, r, dep.value, col.tup()
+
+
+def test_scatter_free_flight_distribution():
+    """Free flight -ln(1-u)/sigma: mean 1/sigma over the events, P(scatter before D) = 1 - exp(-sigma D); a scattered
+    ray starts where the walk left it, in a unit direction, absorbed over the flight only."""
+    rng = np.random.default_rng(3)
+    sigma, D = 2.5, 0.9
+    flights, n = [], 20000
+    for u in rng.random(n).astype(np.float32):
+        sc, r, dep, col = _scatter((1, 2, 3), (0, 0, 1), 1e9, (0.3, 0.0, 1.0), sigma, (1, 1, 1), float(u), 0.3, 0.6)
+        assert sc == 1
+        flights.append(dep)
+        assert abs(r.origin.z - (3 + dep)) < 1e-5 * max(1, dep) and r.origin.x == 1 and r.origin.y == 2
+        dn = math.sqrt(sum(c * c for c in r.direction.tup()))
+        assert abs(dn - 1) < 1e-5
+        assert abs(col[0] - math.exp(-0.3 * dep)) < 1e-5 and col[1] == 1.0 and abs(col[2] - math.exp(-dep)) < 1e-5
+    assert abs(np.mean(flights) - 1 / sigma) < 0.01
+    hits = sum(_scatter((0, 0, 0), (1, 0, 0), D, (0, 0, 0), sigma, (1, 1, 1), float(u), 0.1, 0.2)[0]
+               for u in rng.random(n).astype(np.float32))
+    assert abs(hits / n - (1 - math.exp(-sigma * D))) < 0.01
+
+
+def test_scatter_boundary_and_degenerate_cases():
+    # no scattering coefficient: never scatters, absorbs over the whole segment
+    sc, r, dep, col = _scatter((0, 0, 0), (0, 1, 0), 2.0, (0.5, 0.0, 0.25), 0.0, (1, 0.5, 1), 0.999, 0.5, 0.5)
+    assert sc == 0 and dep == 2.0 and r.origin.tup() == (0, 0, 0) and r.direction.tup() == (0, 1, 0)
+    assert abs(col[0] - math.exp(-1.0)) < 1e-6 and col[1] == 0.5 and abs(col[2] - math.exp(-0.5)) < 1e-6
+    # u == 1: ln(0): no scattering event
+    assert _scatter((0, 0, 0), (0, 1, 0), 2.0, (0, 0, 0), 5.0, (1, 1, 1), 1.0, 0.5, 0.5)[0] == 0
+    # flight exactly at / beyond the boundary is not a scattering event
+    assert _scatter((0, 0, 0), (0, 1, 0), 0.0, (0, 0, 0), 5.0, (1, 1, 1), 0.5, 0.5, 0.5)[0] == 0
+
+
+def test_scatter_render_conserves_and_differs(scenes_dir):
+    """The option changes the picture of a scene with SCATTER materials, leaves one without them alone, and a
+    non-absorbing medium in a furnace does not create energy."""
+    sc = O.LoadedScene(scenes_dir + "/sss_blobs.txt", O.ROTAT_DEGREES)
+    sc.set_resolution(64, 64)
+    a, la = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, 8, iters=2)
+    b, lb = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, 8, iters=2, scatter=1)
+    assert not np.array_equal(a, b) and np.isfinite(b).all() and b.min() >= 0
+    assert int(lb.sum()) > int(la.sum())            # the walk inside the media costs bounces
+    s2 = O.LoadedScene(scenes_dir + "/sampleScene_spec.txt")
+    s2.set_resolution(48, 48)
+    c, _ = O.render(s2.geoms, s2.n_objects, s2.mats, s2.n_materials, s2.camera, 6, iters=1)
+    d, _ = O.render(s2.geoms, s2.n_objects, s2.mats, s2.n_materials, s2.camera, 6, iters=1, scatter=1)
+    assert np.array_equal(c, d)

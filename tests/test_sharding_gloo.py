@@ -130,3 +130,19 @@ def test_band_partition_properties():
     assert sharding.weak_scaled_frame(1920, 1080, 4) == (3840, 2160)          # BASELINE configs[3]
     w8, h8 = sharding.weak_scaled_frame(1920, 1080, 8)
     assert abs(w8 * h8 / (8 * 1920 * 1080) - 1) < 0.01
+
+
+def test_strong_scaling_keeps_the_frame():
+    """bench.py --scaling strong: the configuration's frame itself is cut into `world` tiles (configs[3]: 3840x2160 over
+    8 GPUs), every row owned once; weak scaling grows the frame instead."""
+    load_package()
+    from project3_pathtracer_amd import sharding
+    for world in (1, 2, 4, 8):
+        assert sharding.scaled_frame(3840, 2160, world, "strong") == (3840, 2160)
+        rows = sum(sharding.strip_local_rows(2160, world, r) for r in range(world))
+        assert rows == 2160
+        assert sharding.max_strip_rows(2160, world) * world >= 2160
+    assert sharding.scaled_frame(1920, 1080, 4, "weak") == (3840, 2160)
+    assert sharding.scaled_frame(1920, 1080, 1, "weak") == (1920, 1080)
+    with pytest.raises(ValueError):
+        sharding.scaled_frame(1920, 1080, 2, "sideways")
