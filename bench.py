@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configuration (default 2)")
     ap.add_argument("--steps", type=int, default=None, help="iterations timed (default: the config's spp, at most 4096)")
     ap.add_argument("--warmup", type=int, default=256)      # 50 ms: the GPU clock needs that long to settle (16: -3.5 %)
+    ap.add_argument("--settle-ms", type=float, default=120.0,
+                    help="after the W warm-up steps keep rendering untimed iterations until the GPU has been busy this long "
+                         "(DVFS: a 1 ms warm-up leaves the clock ~16 %% low for the whole of a 4 ms timed region); 0 = off")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = ~1920x1080 pixels per rank of a frame that grows with N; strong = the config's frame cut into N tiles")
     ap.add_argument("--scene", default=None)
@@ -217,15 +220,36 @@ def main():
             torch.cuda.synchronize(dev)
 
     # warmup (untimed): also captures the per-iteration hipGraph
+    t_w = time.perf_counter()
     if args.warmup > 0:
         r.render(1, args.warmup)
     if world > 1:
         frame = gather()
     sync()
+    # clock settle (untimed, reported): the W warm-up steps last W x ~0.2 ms here, and the GPU needs ~50-100 ms of load
+    # to reach the clock it then holds (measured: --steps 20 after --warmup 5: 29.5 G, after --warmup 256: 35.1 G
+    # ray-bounces/s).  The same iterations of the same frame keep being rendered until the device has been busy for
+    # settle_ms; the timed region is untouched: exactly K steps, bracketed as before.
+    settle_iters = 0
+    chunk = 64
+    while args.settle_ms > 0 and (time.perf_counter() - t_w) * 1e3 < args.settle_ms and settle_iters < 65536:
+        r.render(args.warmup + settle_iters + 1, chunk)
+        r.synchronize()
+        settle_iters += chunk
+    if world > 1:
+        # every rank leaves the settle phase at its own iteration count (it only has to be warm); agree on the largest so
+        # that the timed iterations carry the same numbers everywhere (RNG streams are keyed on them)
+        tmp = torch.tensor([float(settle_iters)], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(tmp, op=dist.ReduceOp.MAX)
+        more = int(tmp[0]) - settle_iters
+        if more > 0:
+            r.render(args.warmup + settle_iters + 1, more)
+            settle_iters += more
+    sync()
     r.reset_stats()
 
     # timed region: exactly K steps (+ the one framebuffer gather for N>1)
-    first = args.warmup + 1
+    first = args.warmup + settle_iters + 1
     sync()
     t0 = time.perf_counter()
     r.render(first, args.steps)
@@ -283,6 +307,8 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "warmup_settle": {"extra_untimed_iterations": settle_iters, "settle_ms": args.settle_ms,
+                              "why": "GPU clock ramp (DVFS); the timed region is exactly `steps` iterations"},
             "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": args.scaling if world > 1 else "weak",

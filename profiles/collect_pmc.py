@@ -77,7 +77,7 @@ def main():
     out = os.path.join(ROOT, "gpurun_out", f"pmc_{a.tag}")
     os.makedirs(out, exist_ok=True)
     bench = ["python3", os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup", str(a.warmup),
-             "--no-cpu-baseline", "--traffic-json", "/nonexistent"] + a.bench_args
+             "--no-cpu-baseline", "--settle-ms", "0", "--traffic-json", "/nonexistent"] + a.bench_args
     # the kernel-trace pass times bench.py's DEFAULT run (the command the driver runs, minus the CPU leg), so its
     # average k_bounce duration is comparable with roofline.avg_launch_ms of the committed bench line
     bench_trace = ["python3", os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + a.bench_args

@@ -1,4 +1,4 @@
-// pt_bounce.h -- the per-bounce kernel k_bounce<WG, FIRST, GEOM, COMPACT, NEE> and the nearest-hit machinery behind it
+// pt_bounce.h -- the per-bounce kernel k_bounce<WG, FIRST, GEOM, COMPACT, FEAT> and the nearest-hit machinery behind it
 // (raycastFromCameraKernel fused into bounce 0, one bounce of raytraceRay, stream compaction: see pt_kernels.hip's header).
 // Templates only: each geometry path is instantiated in its own translation unit (pt_bounce_g<N>.hip) so that the seven
 // of them compile in parallel; pt_kernels.hip picks the instance at launch time through bounce_kernel_g<N>().
@@ -937,9 +937,14 @@ __device__ __forceinline__ uint32_t globalPixel(const KParams &p, uint32_t pl)
 // the nearest-hit machinery for the shadow rays.
 // 5 waves per SIMD (<= 96 VGPRs) is where the plain kernels sit and what hides their LDS / pool latency: ask for it, so
 // that a few registers more do not silently drop a wave (4 waves: -5 %).
-template <int WG, bool FIRST, int GEOM, int COMPACT, bool NEE = false>
-__global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(const KParams p, const int bounce)
+// FEAT: optional features built as kernel instances of their own, so that the default path keeps its registers and
+// instruction count (measured: the scattering code alone costs the plain kernel 1.1 % when compiled in):
+// bit 0 = NEE (pt_options.direct_light), bit 1 = MEDIA (pt_options.scatter: subsurface random walk).
+enum { FEAT_NEE = 1, FEAT_MEDIA = 2 };
+template <int WG, bool FIRST, int GEOM, int COMPACT, int FEAT = 0>
+__global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce(const KParams p, const int bounce)
 {
+    constexpr bool NEE = (FEAT & FEAT_NEE) != 0, MEDIA = (FEAT & FEAT_MEDIA) != 0;
     constexpr int NW = WG / 64;
     constexpr bool PRIMS_IN_LDS = (GEOM == GEOM_LDS || GEOM == GEOM_QUEUE || GEOM == GEOM_PAIR);   // GEOM_BVH gathers records from global memory (L1/L2)
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
@@ -1175,7 +1180,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
                     const float refr = s_mats[M_REFR * p.nM + m];
                     const float refl = s_mats[M_REFL * p.nM + m];
                     // subsurface scattering (pt_options.scatter): a SCATTER material that is not a mirror encloses a medium
-                    const bool medium = p.scatter != 0 && s_mats[M_SCAT * p.nM + m] > 0.0f && !(refl > 0.0f);
+                    const bool medium = MEDIA && s_mats[M_SCAT * p.nM + m] > 0.0f && !(refl > 0.0f);
                     const bool diffuse = !(refr > 0.0f) && !(refl > 0.0f) && !medium;
                     if (NEE && diffuse) {
                         // one light, one point on it (the reference's float-seeded samplers), one shadow ray;
@@ -1408,13 +1413,25 @@ __global__ __launch_bounds__(WG, (WG <= 256 && !NEE) ? 5 : 1) void k_bounce(cons
     }
 }
 
-// the k_bounce instance for one geometry path (nullptr: combination not built); defined in pt_bounce_g<GEOM>.hip
-template <int WG, int GEOM>
-static const void *bounce_fn_geom(bool first, int compact, int nee)
+// the k_bounce instance for one geometry path (nullptr: combination not built); defined in pt_bounce_g<GEOM>.hip.
+// feat = FEAT_* bits; the feature instances exist for compaction 1 only, the MEDIA ones for workgroups of 256 and 512
+// (the library's own choices) only.
+template <int WG, int GEOM, int FEAT>
+static const void *bounce_fn_feat(bool first)
 {
-    if (nee) {
+    return first ? (const void *)k_bounce<WG, true, GEOM, 1, FEAT> : (const void *)k_bounce<WG, false, GEOM, 1, FEAT>;
+}
+template <int WG, int GEOM>
+static const void *bounce_fn_geom(bool first, int compact, int feat)
+{
+    if (feat != 0) {
         if (compact != 1) return nullptr;
-        return first ? (const void *)k_bounce<WG, true, GEOM, 1, true> : (const void *)k_bounce<WG, false, GEOM, 1, true>;
+        if (feat == FEAT_NEE) return bounce_fn_feat<WG, GEOM, FEAT_NEE>(first);
+        if (WG == 256 || WG == 512) {
+            if (feat == FEAT_MEDIA) return bounce_fn_feat<(WG == 256 || WG == 512) ? WG : 256, GEOM, FEAT_MEDIA>(first);
+            return bounce_fn_feat<(WG == 256 || WG == 512) ? WG : 256, GEOM, FEAT_NEE | FEAT_MEDIA>(first);
+        }
+        return nullptr;
     }
     if (compact == 1) return first ? (const void *)k_bounce<WG, true, GEOM, 1> : (const void *)k_bounce<WG, false, GEOM, 1>;
     if (compact == 2) return first ? (const void *)k_bounce<WG, true, GEOM, 2> : (const void *)k_bounce<WG, false, GEOM, 2>;
@@ -1422,14 +1439,14 @@ static const void *bounce_fn_geom(bool first, int compact, int nee)
 }
 
 template <int GEOM>
-static const void *bounce_kernel_for(int workgroup, bool first, int compact, int nee)
+static const void *bounce_kernel_for(int workgroup, bool first, int compact, int feat)
 {
     switch (workgroup) {
-    case 64: return bounce_fn_geom<64, GEOM>(first, compact, nee);
-    case 128: return bounce_fn_geom<128, GEOM>(first, compact, nee);
-    case 256: return bounce_fn_geom<256, GEOM>(first, compact, nee);
-    case 512: return bounce_fn_geom<512, GEOM>(first, compact, nee);
-    case 1024: return bounce_fn_geom<1024, GEOM>(first, compact, nee);
+    case 64: return bounce_fn_geom<64, GEOM>(first, compact, feat);
+    case 128: return bounce_fn_geom<128, GEOM>(first, compact, feat);
+    case 256: return bounce_fn_geom<256, GEOM>(first, compact, feat);
+    case 512: return bounce_fn_geom<512, GEOM>(first, compact, feat);
+    case 1024: return bounce_fn_geom<1024, GEOM>(first, compact, feat);
     default: return nullptr;
     }
 }

@@ -3,5 +3,5 @@
 #include "pt_bounce.h"
 
 namespace pt {
-const void *bounce_kernel_g3(int workgroup, bool first, int compact, int nee) { return bounce_kernel_for<3>(workgroup, first, compact, nee); }
+const void *bounce_kernel_g3(int workgroup, bool first, int compact, int feat) { return bounce_kernel_for<3>(workgroup, first, compact, feat); }
 }  // namespace pt

@@ -601,6 +601,13 @@ int configure(pt_ctx *c)
     cfg.geom = o.geom_path == 0 ? (k.nG <= 40 ? 4 : 6) : o.geom_path - 1;
     cfg.compact = o.compaction;
     cfg.nee = k.nlights > 0 ? 1 : 0;             // no lights: nothing to sample, the plain kernels are exact
+    // the scattering kernels only when some material that can hold a medium asks for it: else the plain kernels are exact
+    cfg.media = 0;
+    if (k.scatter)
+        for (const pt_material &m : c->mats)
+            if (m.hasScatter > 0.0f && !(m.hasReflective > 0.0f)) cfg.media = 1;
+    if (cfg.media && !(cfg.workgroup == 256 || cfg.workgroup == 512))
+        return fail(PT_ERR_INVALID, "scatter needs workgroup 0, 256 or 512 (got %d)", cfg.workgroup);
     k.cull = (k.nG > 32 && !getenv("PT_NO_CULL")) ? 1 : 0;
     k.nshard = (cfg.compact == 1) ? pt::NSHARD : 1;
     size_t lds = pt::bounce_lds_bytes(k, cfg);
@@ -859,6 +866,7 @@ int pt_set_options(pt_ctx *c, const pt_options *o)
     if (!(o->lens_radius >= 0.0f) || (o->lens_radius > 0.0f && !(o->focal_distance > 0.0f)))
         return fail(PT_ERR_INVALID, "lens radius %g / focal distance %g", (double)o->lens_radius, (double)o->focal_distance);
     if (o->direct_light && o->compaction != 1) return fail(PT_ERR_INVALID, "direct_light needs compaction 1 (got %d)", o->compaction);
+    if (o->scatter && o->compaction != 1) return fail(PT_ERR_INVALID, "scatter needs compaction 1 (got %d)", o->compaction);
     c->opt = *o;
     c->dirty = true;
     return PT_OK;

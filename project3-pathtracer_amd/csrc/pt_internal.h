@@ -101,6 +101,7 @@ struct LaunchCfg {
                      // 6 batched 4-wide walk + pairs (pt_kernels.hip)
     int compact;     // 0 off, 1 per-wave sharded reservation, 2 workgroup scan + single counter
     int nee;         // 1 = explicit light sampling at diffuse vertices (compact must be 1)
+    int media;       // 1 = subsurface random walk inside SCATTER materials (compact must be 1, workgroup 256 or 512)
 };
 
 // kernels (pt_kernels.hip)

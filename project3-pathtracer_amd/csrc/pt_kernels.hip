@@ -244,24 +244,24 @@ size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg)
 }
 
 // one translation unit per geometry path (pt_bounce_g<N>.hip)
-const void *bounce_kernel_g0(int workgroup, bool first, int compact, int nee);
-const void *bounce_kernel_g1(int workgroup, bool first, int compact, int nee);
-const void *bounce_kernel_g2(int workgroup, bool first, int compact, int nee);
-const void *bounce_kernel_g3(int workgroup, bool first, int compact, int nee);
-const void *bounce_kernel_g4(int workgroup, bool first, int compact, int nee);
-const void *bounce_kernel_g5(int workgroup, bool first, int compact, int nee);
-const void *bounce_kernel_g6(int workgroup, bool first, int compact, int nee);
+const void *bounce_kernel_g0(int workgroup, bool first, int compact, int feat);
+const void *bounce_kernel_g1(int workgroup, bool first, int compact, int feat);
+const void *bounce_kernel_g2(int workgroup, bool first, int compact, int feat);
+const void *bounce_kernel_g3(int workgroup, bool first, int compact, int feat);
+const void *bounce_kernel_g4(int workgroup, bool first, int compact, int feat);
+const void *bounce_kernel_g5(int workgroup, bool first, int compact, int feat);
+const void *bounce_kernel_g6(int workgroup, bool first, int compact, int feat);
 
 static const void *select_bounce(const LaunchCfg &cfg, bool first)
 {
     switch (cfg.geom) {
-    case GEOM_SCALAR: return bounce_kernel_g0(cfg.workgroup, first, cfg.compact, cfg.nee);
-    case GEOM_LDS: return bounce_kernel_g1(cfg.workgroup, first, cfg.compact, cfg.nee);
-    case GEOM_QUEUE: return bounce_kernel_g2(cfg.workgroup, first, cfg.compact, cfg.nee);
-    case GEOM_BVH: return bounce_kernel_g3(cfg.workgroup, first, cfg.compact, cfg.nee);
-    case GEOM_PAIR: return bounce_kernel_g4(cfg.workgroup, first, cfg.compact, cfg.nee);
-    case GEOM_WALK_PAIR: return bounce_kernel_g5(cfg.workgroup, first, cfg.compact, cfg.nee);
-    case GEOM_WALK4: return bounce_kernel_g6(cfg.workgroup, first, cfg.compact, cfg.nee);
+    case GEOM_SCALAR: return bounce_kernel_g0(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1));
+    case GEOM_LDS: return bounce_kernel_g1(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1));
+    case GEOM_QUEUE: return bounce_kernel_g2(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1));
+    case GEOM_BVH: return bounce_kernel_g3(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1));
+    case GEOM_PAIR: return bounce_kernel_g4(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1));
+    case GEOM_WALK_PAIR: return bounce_kernel_g5(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1));
+    case GEOM_WALK4: return bounce_kernel_g6(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1));
     default: return nullptr;
     }
 }
