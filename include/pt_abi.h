@@ -90,7 +90,9 @@ typedef struct pt_options {
                              box pre-test + wave-private queue of (ray, primitive) pairs, exact test on full batches,
                              6 = hierarchy walk with box tests only that queues the leaves it reaches as pairs (large scenes),
                              7 = 4-wide hierarchy walked in full 64-entry batches of (ray, node) entries from a wave-private
-                             LDS stack, leaves queued as pairs (large scenes) */
+                             LDS stack, leaves queued as pairs (large scenes), 8 = the same with the nodes read through L1/L2
+                             instead of an LDS copy (hierarchies too large for the LDS).  Scenes with triangles
+                             (pt_set_meshes) run on 1, 7 or 8 */
     int row_begin;        /* tile rendered by this context: rows [row_begin, row_end) of the frame; */
     int row_end;          /*   0,0 = the whole frame.  RNG streams are keyed on the global pixel index. */
     int use_graph;        /* 1 = replay one captured hipGraph per launch sequence (default), 0 = eager launches */
@@ -145,6 +147,13 @@ int  pt_get_options(pt_ctx *ctx, pt_options *opt);
 int  pt_set_scene(pt_ctx *ctx, const pt_static_geom *geoms, int numberOfGeoms,
                   const pt_material *materials, int numberOfMaterials);
 int  pt_set_camera(pt_ctx *ctx, const pt_camera_data *cam);
+/* Triangles of the MESH geoms (the reference's loader names a .obj file per MESH object and loads nothing,
+ * ref: src/scene.cpp:57-66; its intersection header leaves the triangle test as an option, src/intersections.h:79).
+ * vertices: 9 floats per triangle (v0, v1, v2) in the object space the geom's transform places.  Copied; call after
+ * pt_set_scene (which drops the meshes of the previous scene).  Triangles are tested after the geoms, in the order
+ * given: primitive index = numberOfGeoms + running triangle number. */
+typedef struct pt_mesh { int geom; int n_triangles; const float *vertices; } pt_mesh;
+int  pt_set_meshes(pt_ctx *ctx, const pt_mesh *meshes, int numberOfMeshes);
 int  pt_set_stream(pt_ctx *ctx, void *hip_stream);    /* render on a caller-owned hipStream_t; NULL = own stream */
 
 /* ---- framebuffer: fp32 RGB, 12 B/pixel, index = x + y*W (ref: src/raytraceKernel.cu:98), tile rows only.
@@ -221,6 +230,8 @@ int  pt_scene_get_frame(const pt_scene *s, int frame, pt_static_geom *geoms_out,
                         pt_camera_data *camera_out);
 /* RES override: recomputes fov.x from fov.y as the loader does (ref: src/scene.cpp:204-207) */
 int  pt_camera_set_resolution(pt_camera_data *cam, int width, int height);
+/* triangles of MESH object `object` as read from its .obj file (object space; NULL / 0 when there are none) */
+int  pt_scene_mesh(const pt_scene *s, int object, const float **vertices_out, int *n_triangles_out);
 
 /* ---- several devices of one node behind one handle (single process): device k renders the k-th band of rows,
  *      no communication while rendering, bands gathered to the host or to one device over xGMI peer copies.
@@ -233,6 +244,7 @@ int  pt_multi_set_options(pt_multi *m, const pt_options *opt);      /* row_begin
 int  pt_multi_set_scene(pt_multi *m, const pt_static_geom *geoms, int numberOfGeoms,
                         const pt_material *materials, int numberOfMaterials);
 int  pt_multi_set_camera(pt_multi *m, const pt_camera_data *cam);
+int  pt_multi_set_meshes(pt_multi *m, const pt_mesh *meshes, int numberOfMeshes);
 int  pt_multi_band(const pt_multi *m, int k, int *row_begin, int *row_end);
 int  pt_multi_clear_image(pt_multi *m);
 int  pt_multi_upload_image(pt_multi *m, const float *host_rgb_full_frame);

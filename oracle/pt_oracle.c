@@ -615,16 +615,97 @@ void o_sendImageToPBO(unsigned char *pbo, int npixels, const float *image)
 void o_clearImage(float *image, int npixels) { memset(image, 0, (size_t)npixels * 3 * sizeof(float)); }
 
 /* spec: nearest hit over the whole primitive list; smallest t > 0, ties -> lowest index */
-static int nearest_hit(const o_staticGeom *geoms, int nG, o_ray r, o_vec3 *p, o_vec3 *n, float *t_out)
+/* spec (the reference names the triangle test as optional, src/intersections.h:79, and parses *.obj objects as MESH
+ * without ever loading them, src/scene.cpp:57-66): Moeller-Trumbore in WORLD space on the pre-transformed triangle
+ * (v0, e1 = v1 - v0, e2 = v2 - v0), two-sided, with the ray direction normalised first as the sphere test does;
+ * hit point = getPointOnRay on the normalised ray (the 1e-4 pull-back is in world units here), normal = the triangle's
+ * geometric unit normal n (not flipped), result = distance from the ray origin to that point. */
+float o_triangleIntersectionTest(o_vec3 v0, o_vec3 e1, o_vec3 e2, o_vec3 n, o_ray r, o_vec3 *intersectionPoint, o_vec3 *normal)
+{
+    o_ray rt;
+    rt.origin = r.origin;
+    rt.direction = normalize3(r.direction);
+    o_vec3 pv = cross3(rt.direction, e2);
+    float det = dot3(e1, pv);
+    if (fabsf(det) < 1e-12f) return -1;
+    float inv = 1.0f / det;
+    o_vec3 tv = sub3(rt.origin, v0);
+    float u = dot3(tv, pv) * inv;
+    if (u < 0.0f || u > 1.0f) return -1;
+    o_vec3 qv = cross3(tv, e1);
+    float v = dot3(rt.direction, qv) * inv;
+    if (v < 0.0f || u + v > 1.0f) return -1;
+    float t = dot3(e2, qv) * inv;
+    if (!(t > 0.0f)) return -1;
+    o_vec3 real = o_getPointOnRay(rt, t);
+    *intersectionPoint = real;
+    *normal = n;
+    return length3(sub3(r.origin, real));
+}
+
+void o_triangleToWorld(const o_staticGeom *g, const float v[9], float out12[12])
+{
+    o_vec3 w0 = o_multiplyMV(g->transform, v4(v3(v[0], v[1], v[2]), 1.0f));
+    o_vec3 w1 = o_multiplyMV(g->transform, v4(v3(v[3], v[4], v[5]), 1.0f));
+    o_vec3 w2 = o_multiplyMV(g->transform, v4(v3(v[6], v[7], v[8]), 1.0f));
+    o_vec3 e1 = sub3(w1, w0), e2 = sub3(w2, w0);
+    o_vec3 c = cross3(e1, e2);
+    float l2 = dot3(c, c);
+    o_vec3 n = (l2 > 0.0f) ? normalize3(c) : v3(0, 0, 0);
+    out12[0] = w0.x; out12[1] = w0.y; out12[2] = w0.z;
+    out12[3] = e1.x; out12[4] = e1.y; out12[5] = e1.z;
+    out12[6] = e2.x; out12[7] = e2.y; out12[8] = e2.z;
+    out12[9] = n.x; out12[10] = n.y; out12[11] = n.z;
+}
+
+/* all triangles of a scene state in world space; primitive index of triangle k = nG + k (after every geom) */
+typedef struct { int n; float *w; int *geom; } tri_table;
+
+static int build_tri_table(const o_staticGeom *geoms, int nG, const o_extras *ex, tri_table *tt)
+{
+    tt->n = 0; tt->w = NULL; tt->geom = NULL;
+    if (!ex || ex->n_meshes <= 0) return 0;
+    long long total = 0;
+    for (int k = 0; k < ex->n_meshes; k++) {
+        const o_mesh *m = &ex->meshes[k];
+        if (m->geom < 0 || m->geom >= nG || geoms[m->geom].type != O_MESH || m->n_triangles < 0 || (m->n_triangles > 0 && !m->vertices)) return -6;
+        total += m->n_triangles;
+    }
+    if (total == 0) return 0;
+    tt->w = (float *)malloc((size_t)total * 12 * sizeof(float));
+    tt->geom = (int *)malloc((size_t)total * sizeof(int));
+    if (!tt->w || !tt->geom) return -5;
+    for (int k = 0; k < ex->n_meshes; k++) {
+        const o_mesh *m = &ex->meshes[k];
+        for (int t = 0; t < m->n_triangles; t++) {
+            o_triangleToWorld(&geoms[m->geom], m->vertices + 9 * (size_t)t, tt->w + 12 * (size_t)tt->n);
+            tt->geom[tt->n] = m->geom;
+            tt->n++;
+        }
+    }
+    return 0;
+}
+static void free_tri_table(tri_table *tt) { free(tt->w); free(tt->geom); tt->w = NULL; tt->geom = NULL; tt->n = 0; }
+
+/* nearest hit over the geoms, then the triangles; returns the primitive index (>= nG: triangle index - nG) */
+static int nearest_hit(const o_staticGeom *geoms, int nG, const tri_table *tt, o_ray r, o_vec3 *p, o_vec3 *n, float *t_out)
 {
     int best = -1; float best_t = 0;
     for (int i = 0; i < nG; i++) {
         o_vec3 ip, in; float t;
         if (geoms[i].type == O_SPHERE) t = o_sphereIntersectionTest(&geoms[i], r, &ip, &in);
         else if (geoms[i].type == O_CUBE) t = o_boxIntersectionTest(&geoms[i], r, &ip, &in);
-        else t = -1;                                      /* MESH: parsed, never loaded (ref: src/scene.cpp:57-66) */
+        else t = -1;                                      /* MESH: its triangles follow the geoms */
         if (t > 0 && (best < 0 || t < best_t)) { best = i; best_t = t; *p = ip; *n = in; }
     }
+    if (tt)
+        for (int k = 0; k < tt->n; k++) {
+            const float *w = tt->w + 12 * (size_t)k;
+            o_vec3 ip, in;
+            float t = o_triangleIntersectionTest(v3(w[0], w[1], w[2]), v3(w[3], w[4], w[5]), v3(w[6], w[7], w[8]),
+                                                 v3(w[9], w[10], w[11]), r, &ip, &in);
+            if (t > 0 && (best < 0 || t < best_t)) { best = nG + k; best_t = t; *p = ip; *n = in; }
+        }
     if (t_out) *t_out = best_t;
     return best;
 }
@@ -646,7 +727,7 @@ static void collect_lights(const o_staticGeom *geoms, int nG, const o_material *
     }
 }
 
-static o_vec3 trace_path(const o_staticGeom *geoms, int nG, const o_material *mats, const cam_basis *cb,
+static o_vec3 trace_path(const o_staticGeom *geoms, int nG, const tri_table *tt, const o_material *mats, const cam_basis *cb,
                          const o_options *opt, const light_table *lt, int W, int x, int y, unsigned iteration,
                          int *bounces, unsigned long long *live_in, unsigned long long *shadow_rays)
 {
@@ -667,9 +748,10 @@ static o_vec3 trace_path(const o_staticGeom *geoms, int nG, const o_material *ma
         if (live_in) live_in[b]++;
         o_vec3 p, n;
         float t_hit;
-        int hit = nearest_hit(geoms, nG, r, &p, &n, &t_hit);
+        int hit = nearest_hit(geoms, nG, tt, r, &p, &n, &t_hit);
         if (hit < 0) break;                                        /* background is black */
-        const o_material *m = &mats[geoms[hit].materialid];
+        const o_staticGeom *hg = (hit < nG) ? &geoms[hit] : &geoms[tt->geom[hit - nG]];   /* triangle: its MESH geom */
+        const o_material *m = &mats[hg->materialid];
         if (m->emittance > 0.0f) {                                 /* light: emit and stop */
             if (!suppress) L = add3(L, scale3(m->emittance, mul3(T, m->color)));
             break;
@@ -704,7 +786,7 @@ static o_vec3 trace_path(const o_staticGeom *geoms, int nG, const o_material *ma
             if (cx > 0.0f && cy > 0.0f) {
                 if (shadow_rays) (*shadow_rays)++;
                 o_vec3 hp, hn; float ht;
-                int hs = nearest_hit(geoms, nG, sr, &hp, &hn, &ht);
+                int hs = nearest_hit(geoms, nG, tt, sr, &hp, &hn, &ht);
                 float tol = 1e-3f * ((dist > 1.0f) ? dist : 1.0f);
                 if (hs == lt->prim[j] && fabsf(ht - dist) <= tol) {
                     const o_material *lm = &mats[lg->materialid];
@@ -754,7 +836,8 @@ static o_vec3 trace_path(const o_staticGeom *geoms, int nG, const o_material *ma
              * for objects scaled by more than 2 exceeds RAY_BIAS_AMOUNT: the ray would meet the same surface
              * again from the same side.  The offset therefore adds that pull-back's world length,
              * 1e-4 / |inverseTransform * d|. */
-            o_vec3 v = o_multiplyMV(geoms[hit].inverseTransform, v4(d_in, 0.0f));
+            /* (a triangle is tested in world space: its pull-back is 1e-4 / |d|) */
+            o_vec3 v = (hit < nG) ? o_multiplyMV(geoms[hit].inverseTransform, v4(d_in, 0.0f)) : d_in;
             float pb = 1e-4f * (1.0f / sqrtf(dot3(v, v)));
             o_vec3 nf = (dot3(n, d_in) > 0.0f) ? neg3(n) : n;
             r.origin = add3(p, scale3(O_RAY_BIAS_AMOUNT + pb, neg3(nf)));
@@ -782,32 +865,70 @@ static int validate(const o_staticGeom *geoms, int nG, int nM, const o_cameraDat
     return 0;
 }
 
+/* one scene state (a motion-blur slice, or the static scene) */
+typedef struct { const o_staticGeom *geoms; tri_table tt; light_table lt; cam_basis cb; } scene_state;
+
+static int n_states(const o_extras *ex) { return (ex && ex->n_slices > 0 && ex->slice_geoms) ? ex->n_slices : 1; }
+
+static int build_states(const o_staticGeom *geoms, int nG, const o_material *mats, const o_cameraData *cam,
+                        const o_extras *ex, scene_state **out)
+{
+    const int n = n_states(ex);
+    scene_state *st = (scene_state *)calloc((size_t)n, sizeof(*st));
+    if (!st) return -5;
+    for (int k = 0; k < n; k++) {
+        const int sliced = (ex && ex->n_slices > 0 && ex->slice_geoms);
+        st[k].geoms = sliced ? ex->slice_geoms + (size_t)k * (size_t)nG : geoms;
+        const o_cameraData *c = (sliced && ex->slice_cams) ? &ex->slice_cams[k] : cam;
+        st[k].cb = camera_basis(cam->resolution, c->position, c->view, c->up, cam->fov);
+        collect_lights(st[k].geoms, nG, mats, &st[k].lt);
+        int rc = build_tri_table(st[k].geoms, nG, ex, &st[k].tt);
+        if (rc != 0) { for (int j = 0; j <= k; j++) free_tri_table(&st[j].tt); free(st); return rc; }
+    }
+    *out = st;
+    return 0;
+}
+static void free_states(scene_state *st, int n) { for (int k = 0; k < n; k++) free_tri_table(&st[k].tt); free(st); }
+static const scene_state *state_of(const scene_state *st, int n, unsigned iteration)
+{
+    return &st[n > 1 ? (int)(((iteration - 1u) / (unsigned)O_SLICE_ITERATIONS) % (unsigned)n) : 0];
+}
+
+o_vec3 o_trace_path_ex(const o_staticGeom *geoms, int nG, const o_material *mats, int nM, const o_cameraData *cam,
+                       const o_options *opt, const o_extras *ex, int x, int y, unsigned iteration, int *bounces_out)
+{
+    if (validate(geoms, nG, nM, cam, opt) != 0) return v3(-1, -1, -1);
+    scene_state *st;
+    if (build_states(geoms, nG, mats, cam, ex, &st) != 0) return v3(-1, -1, -1);
+    const int n = n_states(ex);
+    const scene_state *s = state_of(st, n, iteration);
+    if (bounces_out) *bounces_out = 0;
+    o_vec3 L = trace_path(s->geoms, nG, &s->tt, mats, &s->cb, opt, &s->lt, (int)cam->resolution.x, x, y, iteration, bounces_out, NULL, NULL);
+    free_states(st, n);
+    return L;
+}
+
 o_vec3 o_trace_path(const o_staticGeom *geoms, int nG, const o_material *mats, int nM, const o_cameraData *cam,
                     const o_options *opt, int x, int y, unsigned iteration, int *bounces_out)
 {
-    if (validate(geoms, nG, nM, cam, opt) != 0) return v3(-1, -1, -1);
-    cam_basis cb = camera_basis(cam->resolution, cam->position, cam->view, cam->up, cam->fov);
-    light_table lt;
-    collect_lights(geoms, nG, mats, &lt);
-    if (bounces_out) *bounces_out = 0;
-    return trace_path(geoms, nG, mats, &cb, opt, &lt, (int)cam->resolution.x, x, y, iteration, bounces_out, NULL, NULL);
+    return o_trace_path_ex(geoms, nG, mats, nM, cam, opt, NULL, x, y, iteration, bounces_out);
 }
 
 typedef struct {
-    const o_staticGeom *geoms; int nG; const o_material *mats; const cam_basis *cb; const o_options *opt;
+    const scene_state *states; int n_states; int nG; const o_material *mats; const o_options *opt;
     float *image; int W, H; int iter_first, iter_count; int row0, row1;
     unsigned long long *live_in;   /* private per thread, depth entries */
     unsigned long long shadow_rays;
-    const light_table *lt;
 } job;
 
 static void *render_rows(void *arg)
 {
     job *j = (job *)arg;
     for (int it = j->iter_first; it < j->iter_first + j->iter_count; it++) {
+        const scene_state *s = state_of(j->states, j->n_states, (unsigned)it);
         for (int y = j->row0; y < j->row1; y++) {
             for (int x = 0; x < j->W; x++) {
-                o_vec3 L = trace_path(j->geoms, j->nG, j->mats, j->cb, j->opt, j->lt, j->W, x, y, (unsigned)it,
+                o_vec3 L = trace_path(s->geoms, j->nG, &s->tt, j->mats, &s->cb, j->opt, &s->lt, j->W, x, y, (unsigned)it,
                                       NULL, j->live_in, &j->shadow_rays);
                 /* spec: running mean, stateless given (image, iteration) */
                 float *px = &j->image[3 * ((size_t)x + (size_t)y * (size_t)j->W)];
@@ -832,29 +953,36 @@ int o_render_counted(const o_staticGeom *geoms, int nG, const o_material *mats, 
                      const o_options *opt, float *image, int iter_first, int iter_count,
                      unsigned long long *live_in, unsigned long long *shadow_rays, int nthreads)
 {
+    return o_render_ex(geoms, nG, mats, nM, cam, opt, NULL, image, iter_first, iter_count, live_in, shadow_rays, nthreads);
+}
+
+int o_render_ex(const o_staticGeom *geoms, int nG, const o_material *mats, int nM, const o_cameraData *cam,
+                const o_options *opt, const o_extras *ex, float *image, int iter_first, int iter_count,
+                unsigned long long *live_in, unsigned long long *shadow_rays, int nthreads)
+{
     int rc = validate(geoms, nG, nM, cam, opt);
     if (rc != 0) return rc;
     if (!image || iter_first < 1 || iter_count < 0) return -4;
     int W = (int)cam->resolution.x, H = (int)cam->resolution.y;
-    cam_basis cb = camera_basis(cam->resolution, cam->position, cam->view, cam->up, cam->fov);
-    light_table lt;
-    collect_lights(geoms, nG, mats, &lt);
+    scene_state *states;
+    rc = build_states(geoms, nG, mats, cam, ex, &states);
+    if (rc != 0) return rc;
+    const int ns = n_states(ex);
     if (nthreads < 1) nthreads = 1;
     if (nthreads > H) nthreads = H;
     if (nthreads > 256) nthreads = 256;
 
     job jobs[256]; pthread_t th[256];
     unsigned long long *counts = (unsigned long long *)calloc((size_t)nthreads * (size_t)opt->depth, sizeof(*counts));
-    if (!counts) return -5;
+    if (!counts) { free_states(states, ns); return -5; }
     /* rows are dealt in contiguous blocks; each pixel is owned by exactly one thread */
     for (int t = 0; t < nthreads; t++) {
         job *j = &jobs[t];
-        j->geoms = geoms; j->nG = nG; j->mats = mats; j->cb = &cb; j->opt = opt; j->image = image;
+        j->states = states; j->n_states = ns; j->nG = nG; j->mats = mats; j->opt = opt; j->image = image;
         j->W = W; j->H = H; j->iter_first = iter_first; j->iter_count = iter_count;
         j->row0 = (int)((long long)H * t / nthreads); j->row1 = (int)((long long)H * (t + 1) / nthreads);
         j->live_in = counts + (size_t)t * (size_t)opt->depth;
         j->shadow_rays = 0;
-        j->lt = &lt;
     }
     if (nthreads == 1) render_rows(&jobs[0]);
     else {
@@ -870,5 +998,6 @@ int o_render_counted(const o_staticGeom *geoms, int nG, const o_material *mats, 
     if (shadow_rays)
         for (int t = 0; t < nthreads; t++) *shadow_rays += jobs[t].shadow_rays;
     free(counts);
+    free_states(states, ns);
     return 0;
 }

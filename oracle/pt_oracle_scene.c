@@ -358,3 +358,57 @@ void o_scene_free(o_scene *s)
     free(s->objects); free(s->materials);
     memset(s, 0, sizeof *s);
 }
+
+
+/* ------------------------------------------------------------------ */
+/* Wavefront OBJ (MESH objects, ref: src/scene.cpp:57-66 names the file and loads nothing): `v x y z` and            */
+/* `f a b c ...` records, indices 1-based or negative (relative), a/b/c forms, polygons cut into fans around their    */
+/* first vertex; everything else is skipped.  *vertices_out = malloc'ed 9 floats per triangle (o_free_obj).          */
+/* ------------------------------------------------------------------ */
+int o_load_obj(const char *path, float **vertices_out, int *n_triangles_out)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return -1;
+    float *verts = NULL, *tris = NULL;
+    long nv = 0, capv = 0, nt = 0, capt = 0;
+    char line[4096];
+    while (fgets(line, sizeof line, f)) {
+        char *s = line;
+        while (*s == ' ' || *s == '\t') s++;
+        if (s[0] == 'v' && (s[1] == ' ' || s[1] == '\t')) {
+            double x, y, z;
+            if (sscanf(s + 1, "%lf %lf %lf", &x, &y, &z) != 3) continue;
+            if (nv == capv) { capv = capv ? 2 * capv : 256; verts = (float *)realloc(verts, (size_t)capv * 3 * sizeof(float)); }
+            verts[3 * nv] = (float)x; verts[3 * nv + 1] = (float)y; verts[3 * nv + 2] = (float)z;
+            nv++;
+        } else if (s[0] == 'f' && (s[1] == ' ' || s[1] == '\t')) {
+            long idx[64]; int n = 0, bad = 0;
+            char *tok = strtok(s + 1, " \t\r\n");
+            while (tok && n < 64) {
+                long i = strtol(tok, NULL, 10);
+                if (i < 0) i = nv + i + 1;
+                if (i < 1 || i > nv) { bad = 1; break; }
+                idx[n++] = i - 1;
+                tok = strtok(NULL, " \t\r\n");
+            }
+            if (bad) continue;
+            for (int k = 2; k < n; k++) {
+                if (nt == capt) { capt = capt ? 2 * capt : 256; tris = (float *)realloc(tris, (size_t)capt * 9 * sizeof(float)); }
+                const long a[3] = {idx[0], idx[k - 1], idx[k]};
+                for (int j = 0; j < 3; j++) {
+                    tris[9 * nt + 3 * j] = verts[3 * a[j]];
+                    tris[9 * nt + 3 * j + 1] = verts[3 * a[j] + 1];
+                    tris[9 * nt + 3 * j + 2] = verts[3 * a[j] + 2];
+                }
+                nt++;
+            }
+        }
+    }
+    fclose(f);
+    free(verts);
+    *vertices_out = tris;
+    *n_triangles_out = (int)nt;
+    return 0;
+}
+
+void o_free_obj(float *vertices) { free(vertices); }

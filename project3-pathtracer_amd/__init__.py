@@ -74,6 +74,10 @@ class Stats(C.Structure):
                 ("bounce_launches", C.c_ulonglong), ("shadow_rays", C.c_ulonglong)]
 
 
+class Mesh(C.Structure):            # pt_mesh: triangles of one MESH geom, object space, 9 floats each
+    _fields_ = [("geom", C.c_int), ("n_triangles", C.c_int), ("vertices", C.POINTER(C.c_float))]
+
+
 class PtError(RuntimeError):
     pass
 
@@ -119,6 +123,9 @@ def lib():
         "pt_get_options": (i, [vp, P(Options)]),
         "pt_set_scene": (i, [vp, P(StaticGeom), i, P(Material), i]),
         "pt_set_camera": (i, [vp, P(CameraData)]),
+        "pt_set_meshes": (i, [vp, P(Mesh), i]),
+        "pt_multi_set_meshes": (i, [vp, P(Mesh), i]),
+        "pt_scene_mesh": (i, [vp, i, P(P(C.c_float)), P(i)]),
         "pt_set_stream": (i, [vp, vp]),
         "pt_image_bytes": (sz, [vp]),
         "pt_bind_image": (i, [vp, vp]),
@@ -197,6 +204,12 @@ class SceneFile:
             name = C.create_string_buffer(256)
             L.pt_scene_camera_info(h, C.byref(it), name, 256)
             self.iterations, self.image_name = it.value, name.value.decode()
+            # triangles of the MESH objects (object space), {object index: float32 array [n, 9]}
+            self.meshes = {}
+            for k in range(no.value):
+                vp_, nt = C.POINTER(C.c_float)(), C.c_int()
+                if L.pt_scene_mesh(h, k, C.byref(vp_), C.byref(nt)) == PT_OK and nt.value > 0:
+                    self.meshes[k] = np.ctypeslib.as_array(vp_, shape=(nt.value, 9)).astype(np.float32).copy()
         finally:
             L.pt_scene_free(h)
 
@@ -236,6 +249,14 @@ class Renderer:
     def set_scene(self, geoms, n_geoms, mats, n_mats):
         _check(self.L.pt_set_scene(self.h, C.cast(geoms, C.POINTER(StaticGeom)), n_geoms,
                                    C.cast(mats, C.POINTER(Material)), n_mats), "pt_set_scene")
+
+    def set_meshes(self, meshes):
+        """meshes: {geom index: float32 array [n_triangles, 9]} (object space), e.g. SceneFile.meshes"""
+        arrs = [(int(g), np.ascontiguousarray(v, dtype=np.float32).reshape(-1, 9)) for g, v in sorted(meshes.items())]
+        desc = (Mesh * max(1, len(arrs)))()
+        for k, (g, v) in enumerate(arrs):
+            desc[k] = Mesh(g, v.shape[0], v.ctypes.data_as(C.POINTER(C.c_float)))
+        _check(self.L.pt_set_meshes(self.h, desc, len(arrs)), "pt_set_meshes")
 
     def set_camera(self, cam):
         self.cam = CameraData.from_buffer_copy(cam)

@@ -21,10 +21,6 @@ static constexpr uint32_t DEAD = 0xFFFFFFFFu;
 #ifndef PT_DEBUG_BVH
 #define PT_DEBUG_BVH 0
 #endif
-// experiment: the batched walk reads its nodes through L1/L2 instead of an LDS copy (more workgroups per CU)
-#ifndef PT_W4_GLOBAL
-#define PT_W4_GLOBAL 0
-#endif
 static constexpr bool DEBUG_CULL = false;
 static constexpr bool DEBUG_PAIR = PT_DEBUG_PAIR != 0;
 static constexpr bool DEBUG_PHASE = PT_DEBUG_PHASE != 0;     // per-wave shader-clock stamps between the phases of a chunk -> IterState::dbg
@@ -92,7 +88,11 @@ struct Hit {
 //                      per slab), and pushes the children that pass -- inner nodes back on the stack, leaves into the pair
 //                      queues of 4.  Lanes stay busy whatever the length of a single ray's walk: the per-lane walk of 5
 //                      ran 78 loop trips per wave for 28.6 nodes per ray.
-enum { GEOM_SCALAR = 0, GEOM_LDS = 1, GEOM_QUEUE = 2, GEOM_BVH = 3, GEOM_PAIR = 4, GEOM_WALK_PAIR = 5, GEOM_WALK4 = 6 };
+//   7  the same with the 4-wide nodes read through L1/L2 instead of an LDS copy (hierarchies too large for the LDS,
+//                      e.g. triangle meshes of a few thousand faces)
+// Triangle records (type 3, the flattened MESH geoms) are understood by 0, 6 and 7.
+enum { GEOM_SCALAR = 0, GEOM_LDS = 1, GEOM_QUEUE = 2, GEOM_BVH = 3, GEOM_PAIR = 4, GEOM_WALK_PAIR = 5, GEOM_WALK4 = 6,
+       GEOM_WALK4G = 7 };
 
 // Conservative cull for large primitive lists: true when NO lane of the wave can hit the primitive, judged by a
 // padded world-space bounding sphere (centre = transform*(0,0,0,1), radius^2 in the record).  It only ever skips
@@ -407,6 +407,7 @@ __device__ __forceinline__ Hit nearestHitQueued(const KParams &p, const PR *s_pr
 // ---------------------------------------------------------------------------------------------------------------
 struct PairQueue {
     uint32_t *q[2];               // [QCAP] pending pairs, lane | prim << 8: [0] spheres, [1] boxes
+    uint32_t *tq;                 // [QCAP] pending (ray, triangle) pairs (batched walk only)
     unsigned long long *key;      // [64] per owner lane: min over hits of (distance bits << 32 | prim << 8)
     float4 *best;                 // [64] per owner lane: (hit point xyz, meta) of the current minimum
     float4 *org;                  // [64] per owner lane: the ray, (origin.xyz, direction.x) ...
@@ -427,9 +428,11 @@ __device__ __forceinline__ void pairBatch(const KParams &p, const PR *s_prims, c
     uint32_t owner = 0u;
     float4 mine = make_float4(0, 0, 0, 0);
     if (lane < nb + nb2) {
+        // TYPE 3: a batch of (ray, triangle) pairs from the triangle queue
         const uint32_t type = (TYPE == 2u) ? (lane < nb ? 0u : 1u) : TYPE;
-        const uint32_t e = (TYPE == 2u && lane >= nb) ? q.q[1][(head2 + lane - nb) & (QCAP - 1u)]
-                                                      : q.q[TYPE == 2u ? 0u : TYPE][(head + lane) & (QCAP - 1u)];
+        const uint32_t e = (TYPE == 3u) ? q.tq[(head + lane) & (QCAP - 1u)]
+                           : ((TYPE == 2u && lane >= nb) ? q.q[1][(head2 + lane - nb) & (QCAP - 1u)]
+                                                         : q.q[(TYPE == 2u || TYPE == 3u) ? 0u : TYPE][(head + lane) & (QCAP - 1u)]);
         owner = e & 63u;
         const uint32_t prim = e >> 8;
         const float4 oo = q.org[owner];
@@ -445,13 +448,17 @@ __device__ __forceinline__ void pairBatch(const KParams &p, const PR *s_prims, c
         }
         float t;
         uint32_t face;
-        const bool ch = candidateT<FIRST>(type, inv, o, d, ro, rd, t, face);
+        const bool ch = candidateT<FIRST, TYPE == 3u>(type, inv, o, d, ro, rd, t, face);
         if (DEBUG_PAIR) { const uint64_t mm = __ballot(ch); if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicAdd((unsigned long long *)q.dbg + 2 + (TYPE & 1u), (unsigned long long)__popcll(mm)); }
         if (ch) {
-            const float4 f0 = iv[3], f1 = iv[4], f2 = iv[5];          // fwd rows follow the inverse rows
-            const float fwd[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
             f3 real;
-            const float dist = hitPoint(fwd, o, ro, rd, t, real);
+            float dist;
+            if (TYPE == 3u) dist = hitPointTriangle(o, ro, rd, t, real);
+            else {
+                const float4 f0 = iv[3], f1 = iv[4], f2 = iv[5];          // fwd rows follow the inverse rows
+                const float fwd[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
+                dist = hitPoint(fwd, o, ro, rd, t, real);
+            }
             if (dist > 0) {                                  // same admission test as the direct path: t > 0
                 mykey = ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned long long)(prim << 8);
                 mine = make_float4(real.x, real.y, real.z, __uint_as_float((prim << 8) | (face << 28)));
@@ -607,7 +614,7 @@ __device__ __forceinline__ Hit nearestHitWalkPairs(const KParams &p, const Prim 
         const int g = p.big[k];
         const_u32_ptr hp = (const_u32_ptr)(uintptr_t)(p.prims + g);
         const uint32_t type = hp[0];
-        if (type > 1u) continue;
+        if (type == 2u || type > 3u) continue;
         const_u32_ptr bq = (const_u32_ptr)(uintptr_t)(p.box_world + 8 * g);
         const float x0 = __builtin_fmaf(__uint_as_float(bq[0]), dinv.x, oinv.x), x1 = __builtin_fmaf(__uint_as_float(bq[4]), dinv.x, oinv.x);
         const float y0 = __builtin_fmaf(__uint_as_float(bq[1]), dinv.y, oinv.y), y1 = __builtin_fmaf(__uint_as_float(bq[5]), dinv.y, oinv.y);
@@ -736,12 +743,25 @@ __device__ __forceinline__ Hit nearestHitWalkPairs(const KParams &p, const Prim 
 // GEOM_WALK4
 // ---------------------------------------------------------------------------------------------------------------
 static constexpr uint32_t W4_STACK = 384;                              // traversal entries per wave
-static constexpr uint32_t WALK4_EXTRA_BYTES = 64 * 32 + W4_STACK * 4;  // per wave, behind the pair queue: ray reciprocals, stack
+static constexpr uint32_t WALK4_EXTRA_BYTES = 64 * 32 + W4_STACK * 4 + QCAP * 4;  // per wave, behind the pair queue: ray reciprocals, stack, triangle queue
 struct Walk4 {
     const unsigned char *nodes;   // LDS copy of the 4-wide hierarchy (ptd::W4_FLOATS floats per node)
     float4 *inv;                  // [64][2] per owner lane: (1/d.xyz, -o.x/d.x) (-o.y/d.y, -o.z/d.z, near-plane byte offsets, 0)
-    uint32_t *stack;              // [W4_STACK] owner lane | child word (bit 31 leaf, bit 30 type, bits 6..29 index)
+    uint32_t *stack;              // [W4_STACK] owner lane | child word (bit 31 leaf, bit 30 cube, bit 29 triangle, bits 6..28 index)
 };
+
+// append the lanes' (ray, triangle) pairs and run a batch when one is full; every lane of the wave must make the call
+template <bool FIRST>
+__device__ __forceinline__ void pushTriangles(const KParams &p, const Prim *prims, const PairQueue &q, uint32_t &thead, uint32_t &ttail,
+                                              bool is_tri, uint32_t g, uint32_t lane, uint32_t owner)
+{
+    const uint64_t m = __ballot(is_tri);
+    if (m == 0ull) return;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (is_tri) q.tq[(ttail + rank) & (QCAP - 1u)] = owner | (g << 8);
+    ttail += (uint32_t)__popcll(m);
+    if (ttail - thead >= 64u) { pairBatch<3u, FIRST>(p, prims, q, thead, 64u, lane); thead += 64u; }
+}
 
 // Must be entered by all 64 lanes of the wave.  prims: global records (gathered per lane through L1/L2).
 template <bool FIRST>
@@ -752,6 +772,7 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
     q.org[lane] = make_float4(o.x, o.y, o.z, d.x);
     q.dir[lane] = make_float2(d.y, d.z);
     uint32_t head[2] = {0u, 0u}, tail[2] = {0u, 0u};        // wave-uniform
+    uint32_t thead = 0u, ttail = 0u;                         // the triangle queue
     const f3 dinv = approxInverse(d);
     const f3 oinv = mk(-(o.x * dinv.x), -(o.y * dinv.y), -(o.z * dinv.z));
     {
@@ -774,7 +795,8 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
         const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
         const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
         const bool pass = valid && tn <= tf;
-        pushPairs<FIRST>(p, prims, q, head, tail, pass && type == 0u, pass && type == 1u, (uint32_t)g, lane, lane);
+        if (type == 3u) pushTriangles<FIRST>(p, prims, q, thead, ttail, pass, (uint32_t)g, lane, lane);
+        else pushPairs<FIRST>(p, prims, q, head, tail, pass && type == 0u, pass && type == 1u, (uint32_t)g, lane, lane);
     }
     // (no flush here: the pairs wait for the leaves' pairs to fill their batches.  A bound from the walls would prune
     // nothing in a closed room -- the whole hierarchy lies in front of them -- and a full batch runs as soon as 64 pairs
@@ -802,10 +824,11 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
         top -= nb;
         if (DEBUG_BVH) { dbg_steps++; dbg_entries += nb; }
         const bool leaf = act && (e >> 31) != 0u;
-        const uint32_t owner = e & 63u, index = (e >> 6) & 0xFFFFFFu;
+        const uint32_t owner = e & 63u, index = (e >> 6) & 0x7FFFFFu;
         if (__ballot(leaf) != 0ull) {
-            const bool cube = (e & 0x40000000u) != 0u;
-            pushPairs<FIRST>(p, prims, q, head, tail, leaf && !cube, leaf && cube, index, lane, owner);
+            const bool cube = (e & 0x40000000u) != 0u, tri = (e & 0x20000000u) != 0u;
+            pushPairs<FIRST>(p, prims, q, head, tail, leaf && !cube && !tri, leaf && cube, index, lane, owner);
+            if (p.ntri > 0) pushTriangles<FIRST>(p, prims, q, thead, ttail, leaf && tri, index, lane, owner);
         }
         const bool inner = act && (e >> 31) == 0u;
         const uint64_t im = __ballot(inner);
@@ -842,6 +865,7 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
         }
     }
     flushPairs<FIRST>(p, prims, q, head, tail, lane);
+    if (ttail != thead) pairBatch<3u, FIRST>(p, prims, q, thead, ttail - thead, lane);
     wave_lds_fence();
     const uint64_t dbg_vm = DEBUG_BVH ? __ballot(valid) : 0ull;
     if (DEBUG_BVH && lane == 0) {
@@ -871,6 +895,7 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
         h.p = mk(b.x, b.y, b.z);
         h.material = P.material;
         if (P.type == 0u) h.n = sphereNormal(h.p, mk(P.cx, P.cy, P.cz));
+        else if (P.type == 3u) h.n = mk(P.fwd[0], P.fwd[1], P.fwd[2]);
         else {
             const float4 fn = reinterpret_cast<const float4 *>(p.face_n)[prim * 8u + face];
             h.n = mk(fn.x, fn.y, fn.z);
@@ -886,7 +911,7 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const PrimPad *s_pri
                                           f3 o, f3 d, bool want, uint32_t lane)
 {
     if (GEOM == GEOM_QUEUE) return nearestHitQueued<FIRST>(p, s_prims, wq, o, d, want, lane);
-    if (GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR || GEOM == GEOM_WALK4) {
+    if (GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR || GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) {
         PairQueue pq;
         unsigned char *b = reinterpret_cast<unsigned char *>(wq.rec);         // same LDS region as the hit queue
         pq.q[0] = reinterpret_cast<uint32_t *>(b);
@@ -896,11 +921,13 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const PrimPad *s_pri
         pq.org = reinterpret_cast<float4 *>(b + 2 * QCAP * 4 + 64 * 8 + 64 * 16);
         pq.dir = reinterpret_cast<float2 *>(b + 2 * QCAP * 4 + 64 * 8 + 2 * 64 * 16);
         pq.dbg = p.st->dbg;
-        if (GEOM == GEOM_WALK4) {
+        pq.tq = nullptr;
+        if (GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) {
             Walk4 w4;
-            w4.nodes = PT_W4_GLOBAL ? reinterpret_cast<const unsigned char *>(p.bvh4) : reinterpret_cast<const unsigned char *>(s_nodes);
+            w4.nodes = (GEOM == GEOM_WALK4G) ? reinterpret_cast<const unsigned char *>(p.bvh4) : reinterpret_cast<const unsigned char *>(s_nodes);
             w4.inv = reinterpret_cast<float4 *>(b + PAIR_QUEUE_BYTES);
             w4.stack = reinterpret_cast<uint32_t *>(b + PAIR_QUEUE_BYTES + 64 * 32);
+            pq.tq = reinterpret_cast<uint32_t *>(b + PAIR_QUEUE_BYTES + 64 * 32 + W4_STACK * 4);
             return nearestHitWalk4<FIRST>(p, p.prims, w4, pq, o, d, want, lane);
         }
         if (GEOM == GEOM_WALK_PAIR) return nearestHitWalkPairs<FIRST>(p, p.prims, s_nodes, pq, o, d, want, lane);
@@ -954,12 +981,12 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
     const float4 *s_nodes = reinterpret_cast<const float4 *>(smem + prim_bytes);
     // pair queue: the same region holds the primitives' padded boxes (2 float4 each; relative to the eye for camera rays)
     const int node_bytes = (GEOM == GEOM_BVH || GEOM == GEOM_WALK_PAIR) ? p.nnodes * (int)sizeof(BvhNode)
-                           : (GEOM == GEOM_WALK4 ? (PT_W4_GLOBAL ? 0 : ((p.nnodes4 * W4_FLOATS * 4 + 127) & ~127))
+                           : (GEOM == GEOM_WALK4 ? ((p.nnodes4 * W4_FLOATS * 4 + 127) & ~127)
                                                  : (GEOM == GEOM_PAIR ? p.nG * 32 * (NEE ? 2 : 1) : 0));
     unsigned char *s_queue = smem + prim_bytes + node_bytes;
     constexpr int WAVE_LDS = (GEOM == GEOM_QUEUE) ? (int)WAVE_QUEUE_BYTES
                              : ((GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR) ? (int)PAIR_QUEUE_BYTES
-                                : (GEOM == GEOM_WALK4 ? (int)(PAIR_QUEUE_BYTES + WALK4_EXTRA_BYTES) : 0));
+                                : ((GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) ? (int)(PAIR_QUEUE_BYTES + WALK4_EXTRA_BYTES) : 0));
     const int queue_bytes = NW * WAVE_LDS;
     float *s_mats = reinterpret_cast<float *>(s_queue + queue_bytes);
     const int mat_words = (p.nM * M_PLANES + 3) & ~3;
@@ -999,7 +1026,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
         uint4 *dst = reinterpret_cast<uint4 *>(smem + prim_bytes);
         for (int k = tid; k < p.nnodes * 2; k += WG) dst[k] = src[k];
     }
-    if (GEOM == GEOM_WALK4 && !PT_W4_GLOBAL) {
+    if (GEOM == GEOM_WALK4) {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.bvh4);
         uint4 *dst = reinterpret_cast<uint4 *>(smem + prim_bytes);
         for (int k = tid; k < p.nnodes4 * (W4_FLOATS / 4); k += WG) dst[k] = src[k];
@@ -1257,7 +1284,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                         const float4 *iv = reinterpret_cast<const float4 *>(HP->inv);
                         const float4 i0 = iv[0], i1 = iv[1], i2 = iv[2];
                         const float inv[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
-                        const f3 v = mulMV(inv, d, 0.0f);
+                        const f3 v = (HP->type == 3u) ? d : mulMV(inv, d, 0.0f);      // a triangle is tested in world space
                         bias = 0.0002f + 1e-4f * rsqrt_rn(dot(v, v));
                     } else if (refr > 0.0f) {
                         const float ior = s_mats[M_IOR * p.nM + m];
@@ -1284,7 +1311,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                             const float4 *iv = reinterpret_cast<const float4 *>(HP->inv);
                             const float4 i0 = iv[0], i1 = iv[1], i2 = iv[2];
                             const float inv[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
-                            const f3 v = mulMV(inv, d, 0.0f);
+                            const f3 v = (HP->type == 3u) ? d : mulMV(inv, d, 0.0f);  // a triangle is tested in world space
                             bias = 0.0002f + 1e-4f * rsqrt_rn(dot(v, v));
                         }
                     } else if (refl > 0.0f) {

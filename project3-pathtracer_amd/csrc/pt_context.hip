@@ -64,6 +64,9 @@ struct pt_ctx {
     std::vector<pt_static_geom> geoms;
     std::vector<pt_material> mats;
     pt_camera_data cam;
+    // triangles of the MESH geoms (pt_set_meshes), object space: 9 floats each + the geom they belong to
+    std::vector<float> tri_obj;
+    std::vector<int> tri_geom;
 
     // device state
     bool dirty = true;          // scene / camera / options changed since the last configure
@@ -213,9 +216,9 @@ void build_bvh(const std::vector<Aabb> &boxes, std::vector<int> &idx, size_t lo,
 // node i is i + 1, the right child is nodes[i + 1].skip): a wide node takes the two children of a binary node and keeps
 // replacing the child with the largest box by that child's own two children until it has four (or only leaves are left).
 // Record = ptd::W4_FLOATS floats: per axis the four children's lo planes then their hi planes (x: [0..8), y: [8..16),
-// z: [16..24)), then four child words (bit 31 leaf, bit 30 primitive type, bits 6..29 node / primitive index; the low
+// z: [16..24)), then four child words (bit 31 leaf, bit 30 cube, bit 29 triangle, bits 6..28 node / primitive index; the low
 // six bits stay free for the owner lane of a traversal entry).  An empty child has lo = +3e38, hi = -3e38: no ray passes.
-int build_wide4(const std::vector<ptd::BvhNode> &bin, const std::vector<pt_static_geom> &geoms, int b, int depth,
+int build_wide4(const std::vector<ptd::BvhNode> &bin, const std::vector<int> &ptype, int b, int depth,
                 std::vector<float> &out, int &maxdepth)
 {
     auto is_leaf = [&](int i) { return bin[(size_t)i].prim >= 0; };
@@ -247,9 +250,9 @@ int build_wide4(const std::vector<ptd::BvhNode> &bin, const std::vector<pt_stati
             for (int a = 0; a < 3; ++a) { lo[a] = n.lo[a]; hi[a] = n.hi[a]; }
             if (n.prim >= 0) {
                 const uint32_t prim = (uint32_t)n.prim & 0x3FFFFFFFu;
-                word = 0x80000000u | (geoms[prim].type == PT_CUBE ? 0x40000000u : 0u) | (prim << 6);
+                word = 0x80000000u | (ptype[prim] == PT_CUBE ? 0x40000000u : 0u) | (ptype[prim] == 3 ? 0x20000000u : 0u) | (prim << 6);
             } else {
-                word = (uint32_t)build_wide4(bin, geoms, kids[(size_t)c], depth + 1, out, maxdepth) << 6;
+                word = (uint32_t)build_wide4(bin, ptype, kids[(size_t)c], depth + 1, out, maxdepth) << 6;
             }
         }
         float *rec = out.data() + (size_t)me * ptd::W4_FLOATS;       // (re-fetched: the recursion grows the vector)
@@ -334,7 +337,44 @@ int configure(pt_ctx *c)
         k.strip_shift = 28u + lg;
         k.strip_magic = (uint32_t)(((1ull << k.strip_shift) + k.strip_span - 1ull) / k.strip_span);
     }
-    k.nG = (int)c->geoms.size();
+    // triangles of the MESH geoms in world space (12 floats each: v0, e1, e2, unit normal), evaluated with multiplyMV's
+    // operation order; they are primitives of their own behind the geoms: index = number of geoms + triangle number
+    const size_t nGeoms = c->geoms.size(), nT = c->tri_geom.size(), nP = nGeoms + nT;
+    std::vector<float> triw(nT * 12);
+    for (size_t t = 0; t < nT; ++t) {
+        const pt_mat4 &m = c->geoms[(size_t)c->tri_geom[t]].transform;
+        float w[3][3];
+        for (int j = 0; j < 3; ++j) {
+            const float x = c->tri_obj[9 * t + 3 * (size_t)j], y = c->tri_obj[9 * t + 3 * (size_t)j + 1], z = c->tri_obj[9 * t + 3 * (size_t)j + 2];
+            w[j][0] = (m.x.x * x) + (m.x.y * y) + (m.x.z * z) + (m.x.w * 1.0f);
+            w[j][1] = (m.y.x * x) + (m.y.y * y) + (m.y.z * z) + (m.y.w * 1.0f);
+            w[j][2] = (m.z.x * x) + (m.z.y * y) + (m.z.z * z) + (m.z.w * 1.0f);
+        }
+        float *o12 = &triw[12 * t];
+        const v3 e1 = {w[1][0] - w[0][0], w[1][1] - w[0][1], w[1][2] - w[0][2]}, e2 = {w[2][0] - w[0][0], w[2][1] - w[0][1], w[2][2] - w[0][2]};
+        const v3 cr = cross3(e1, e2);
+        const float l2 = cr.x * cr.x + cr.y * cr.y + cr.z * cr.z;
+        const v3 n = (l2 > 0.0f) ? normalize3(cr) : v3{0, 0, 0};
+        o12[0] = w[0][0]; o12[1] = w[0][1]; o12[2] = w[0][2];
+        o12[3] = e1.x; o12[4] = e1.y; o12[5] = e1.z;
+        o12[6] = e2.x; o12[7] = e2.y; o12[8] = e2.z;
+        o12[9] = n.x; o12[10] = n.y; o12[11] = n.z;
+    }
+    // padded world box of triangle t (culling only), same padding rule as prim_bounds
+    auto tri_bounds = [&](size_t t, double rel, double abs_pad) {
+        const float *w = &triw[12 * t];
+        Aabb b;
+        for (int a = 0; a < 3; ++a) {
+            const double p0 = w[a], p1 = (double)w[a] + w[3 + a], p2 = (double)w[a] + w[6 + a];
+            const double lo = std::min(p0, std::min(p1, p2)), hi = std::max(p0, std::max(p1, p2));
+            const double cc = 0.5 * (lo + hi), h = 0.5 * (hi - lo) * rel + abs_pad + 1e-6 * fabs(cc);
+            b.lo[a] = (float)(cc - h);
+            b.hi[a] = (float)(cc + h);
+        }
+        return b;
+    };
+    k.nG = (int)nP;
+    k.ntri = (int)nT;
     k.nM = (int)c->mats.size();
     k.depth = o.depth;
     k.rr_start = o.rr_start;
@@ -342,7 +382,7 @@ int configure(pt_ctx *c)
 
     // scene -> device records
     {
-        std::vector<ptd::Prim> prims(c->geoms.size() ? c->geoms.size() : 1);
+        std::vector<ptd::Prim> prims(nP ? nP : 1);
         memset(prims.data(), 0, prims.size() * sizeof(ptd::Prim));
         for (size_t i = 0; i < c->geoms.size(); ++i) {
             const pt_static_geom &g = c->geoms[i];
@@ -376,6 +416,24 @@ int configure(pt_ctx *c)
             if (orthogonal) rad = (g.type == PT_SPHERE) ? 0.5 * maxlen : 0.5 * sqrt(sumsq);   // r*s_max / half diagonal
             else rad = (g.type == PT_SPHERE) ? 0.5 * sqrt(sumsq) : 0.5 * sum;                  // Frobenius / triangle bound
             rad = rad * 1.02 + 1e-3;
+            p.bound_r2 = (float)(rad * rad);
+        }
+        for (size_t t = 0; t < nT; ++t) {
+            ptd::Prim &p = prims[nGeoms + t];
+            const float *w = &triw[12 * t];
+            p.type = 3u;
+            p.material = (uint32_t)c->geoms[(size_t)c->tri_geom[t]].materialid;
+            for (int q = 0; q < 9; ++q) p.inv[q] = w[q];
+            p.fwd[0] = w[9]; p.fwd[1] = w[10]; p.fwd[2] = w[11];
+            const double cx = w[0] + (w[3] + w[6]) / 3.0, cy = w[1] + (w[4] + w[7]) / 3.0, cz = w[2] + (w[5] + w[8]) / 3.0;
+            double r2 = 0.0;
+            for (int j = 0; j < 3; ++j) {
+                const double px = w[0] + (j == 1 ? w[3] : (j == 2 ? w[6] : 0.0)) - cx, py = w[1] + (j == 1 ? w[4] : (j == 2 ? w[7] : 0.0)) - cy,
+                             pz = w[2] + (j == 1 ? w[5] : (j == 2 ? w[8] : 0.0)) - cz;
+                r2 = std::max(r2, px * px + py * py + pz * pz);
+            }
+            const double rad = sqrt(r2) * 1.02 + 1e-3;
+            p.cx = (float)cx; p.cy = (float)cy; p.cz = (float)cz;
             p.bound_r2 = (float)(rad * rad);
         }
         // direct lighting: emissive primitives in list order (at most 16), their surface area from getRadiuses'
@@ -427,6 +485,9 @@ int configure(pt_ctx *c)
             ro[4 * i + 0] = (m.x.x * ex) + (m.x.y * ey) + (m.x.z * ez) + (m.x.w * 1.0f);
             ro[4 * i + 1] = (m.y.x * ex) + (m.y.y * ey) + (m.y.z * ez) + (m.y.w * 1.0f);
             ro[4 * i + 2] = (m.z.x * ex) + (m.z.y * ey) + (m.z.z * ez) + (m.z.w * 1.0f);
+        }
+        for (size_t t = 0; t < nT; ++t) {
+            ro[4 * (nGeoms + t) + 0] = c->cam.position.x; ro[4 * (nGeoms + t) + 1] = c->cam.position.y; ro[4 * (nGeoms + t) + 2] = c->cam.position.z;
         }
         if (c->d_ro_eye) { (void)hipFree(c->d_ro_eye); c->d_ro_eye = nullptr; }
         HIP_TRY(hipMalloc((void **)&c->d_ro_eye, ro.size() * sizeof(float)));
@@ -481,10 +542,10 @@ int configure(pt_ctx *c)
         // ... and a wave of camera rays covers a small solid angle: the padded world box of every primitive,
         // relative to the eye, lets a wave skip the primitives none of its rays can reach (culling only)
         std::vector<float> be(prims.size() * 8, 0.0f), bw(prims.size() * 8, 0.0f);
-        for (size_t i = 0; i < c->geoms.size(); ++i) {
+        for (size_t i = 0; i < nP; ++i) {
             // hit-or-miss culling only (no distance pruning): the padding just has to cover fp32 rounding (1e-6 of the
             // coordinates), and a tight one keeps a ray that leaves a wall (0.0002 above it) outside that wall's box
-            const Aabb b = prim_bounds(c->geoms[i], 1.005, 1e-4);
+            const Aabb b = i < nGeoms ? prim_bounds(c->geoms[i], 1.005, 1e-4) : tri_bounds(i - nGeoms, 1.005, 1e-4);
             for (int a = 0; a < 3; ++a) { bw[8 * i + (size_t)a] = b.lo[a]; bw[8 * i + 4 + (size_t)a] = b.hi[a]; }
             const double e[3] = {c->cam.position.x, c->cam.position.y, c->cam.position.z};
             for (int a = 0; a < 3; ++a) {
@@ -528,13 +589,15 @@ int configure(pt_ctx *c)
 
     // culling hierarchy (used by geom_path 4 / large scenes); MESH primitives have no geometry and stay out
     {
-        std::vector<Aabb> boxes(c->geoms.size());
+        std::vector<Aabb> boxes(nP);
+        std::vector<int> ptype(nP, 3);                           // primitive type by expanded index (3 = triangle)
+        for (size_t i = 0; i < nGeoms; ++i) ptype[i] = c->geoms[i].type;
         std::vector<int> idx;
         float slo[3] = {0, 0, 0}, shi[3] = {0, 0, 0};
         bool first_box = true;
-        for (size_t i = 0; i < c->geoms.size(); ++i) {
-            boxes[i] = prim_bounds(c->geoms[i], 1.005, 1e-4);    // hit-or-miss culling: the distance pruning has its own slack
-            if (c->geoms[i].type == PT_MESH) continue;
+        for (size_t i = 0; i < nP; ++i) {
+            boxes[i] = i < nGeoms ? prim_bounds(c->geoms[i], 1.005, 1e-4) : tri_bounds(i - nGeoms, 1.005, 1e-4);    // hit-or-miss culling: the distance pruning has its own slack
+            if (ptype[i] == PT_MESH) continue;
             for (int a = 0; a < 3; ++a) {
                 if (first_box || boxes[i].lo[a] < slo[a]) slo[a] = boxes[i].lo[a];
                 if (first_box || boxes[i].hi[a] > shi[a]) shi[a] = boxes[i].hi[a];
@@ -544,23 +607,23 @@ int configure(pt_ctx *c)
         float sext = 0.0f;
         for (int a = 0; a < 3; ++a) if (shi[a] - slo[a] > sext) sext = shi[a] - slo[a];
         k.nbig = 0;
-        for (size_t i = 0; i < c->geoms.size(); ++i) {
-            if (c->geoms[i].type == PT_MESH) continue;
+        for (size_t i = 0; i < nP; ++i) {
+            if (ptype[i] == PT_MESH) continue;
             float ext = 0.0f;
             for (int a = 0; a < 3; ++a) if (boxes[i].hi[a] - boxes[i].lo[a] > ext) ext = boxes[i].hi[a] - boxes[i].lo[a];
             // a primitive spanning > 40 % of the scene goes to the always-tested list (at most 16 of them)
-            if (ext > 0.4f * sext && k.nbig < 16 && c->geoms.size() > 16) k.big[k.nbig++] = (int)i;
+            if (ext > 0.4f * sext && k.nbig < 16 && nP > 16) k.big[k.nbig++] = (int)i;
             else idx.push_back((int)i);
         }
         std::vector<ptd::BvhNode> nodes;
         if (!idx.empty()) build_bvh(boxes, idx, 0, idx.size(), nodes);
         for (auto &nd : nodes)
-            if (nd.prim >= 0) nd.prim |= (c->geoms[(size_t)nd.prim].type == PT_CUBE ? 1 : 0) << 30;
+            if (nd.prim >= 0) nd.prim |= (ptype[(size_t)nd.prim] == PT_CUBE ? 1 : 0) << 30;
         k.nnodes = (int)nodes.size();
         {
             std::vector<float> wide;
             int wdepth = 0;
-            if (!nodes.empty()) build_wide4(nodes, c->geoms, 0, 1, wide, wdepth);
+            if (!nodes.empty()) build_wide4(nodes, ptype, 0, 1, wide, wdepth);
             k.nnodes4 = (int)(wide.size() / ptd::W4_FLOATS);
             k.wdepth = wdepth;
             if (c->d_bvh4) { (void)hipFree(c->d_bvh4); c->d_bvh4 = nullptr; }
@@ -599,6 +662,13 @@ int configure(pt_ctx *c)
     // library choice: the pair queue's pre-test is linear in the primitive count, the hierarchy walks logarithmic:
     // measured crossover near 40 primitives (profiles/r01/crossover_pair_vs_walk.txt); above it the batched 4-wide walk
     cfg.geom = o.geom_path == 0 ? (k.nG <= 40 ? 4 : 6) : o.geom_path - 1;
+    if (k.ntri > 0) {
+        // triangle records are understood by the scalar loop and the batched walks only
+        if (o.geom_path == 0) cfg.geom = 6;
+        else if (!(cfg.geom == 0 || cfg.geom == 6 || cfg.geom == 7))
+            return fail(PT_ERR_INVALID, "scenes with triangle meshes need geom_path 0, 1, 7 or 8 (got %d)", o.geom_path);
+        if (k.nG >= (1 << 20)) return fail(PT_ERR_INVALID, "%d primitives (triangles included): at most %d", k.nG, (1 << 20) - 1);
+    }
     cfg.compact = o.compaction;
     cfg.nee = k.nlights > 0 ? 1 : 0;             // no lights: nothing to sample, the plain kernels are exact
     // the scattering kernels only when some material that can hold a medium asks for it: else the plain kernels are exact
@@ -611,7 +681,7 @@ int configure(pt_ctx *c)
     k.cull = (k.nG > 32 && !getenv("PT_NO_CULL")) ? 1 : 0;
     k.nshard = (cfg.compact == 1) ? pt::NSHARD : 1;
     size_t lds = pt::bounce_lds_bytes(k, cfg);
-    if (cfg.geom == 6 && o.workgroup == 0) {
+    if ((cfg.geom == 6 || cfg.geom == 7) && o.workgroup == 0) {
         // the batched walk keeps 7.5 KiB of LDS per wave beside the node copy: take the workgroup size that puts most
         // waves on a CU (a larger workgroup shares one node copy among more waves)
         int best_wg = cfg.workgroup;
@@ -627,7 +697,7 @@ int configure(pt_ctx *c)
         lds = pt::bounce_lds_bytes(k, cfg);
     }
     if (cfg.geom == 6 && lds > 96 * 1024 && o.geom_path == 0) {
-        cfg.geom = 5;                              // node copy too large for two workgroups per CU: the per-lane walk
+        cfg.geom = 7;                              // node copy too large for the LDS: the same walk, nodes through L1/L2
         cfg.workgroup = o.workgroup ? o.workgroup : 256;
         lds = pt::bounce_lds_bytes(k, cfg);
     }
@@ -852,7 +922,7 @@ int pt_set_options(pt_ctx *c, const pt_options *o)
     const int wg = o->workgroup;
     if (!(wg == 0 || wg == 64 || wg == 128 || wg == 256 || wg == 512 || wg == 1024))
         return fail(PT_ERR_INVALID, "workgroup %d not one of 0,64,128,256,512,1024", wg);
-    if (o->geom_path < 0 || o->geom_path > 7) return fail(PT_ERR_INVALID, "geom_path %d not in 0..7", o->geom_path);
+    if (o->geom_path < 0 || o->geom_path > 8) return fail(PT_ERR_INVALID, "geom_path %d not in 0..8", o->geom_path);
     if (o->row_begin < 0 || o->row_end < o->row_begin) return fail(PT_ERR_INVALID, "tile rows [%d,%d)", o->row_begin, o->row_end);
     if (o->strip_rows < 0 || (o->strip_rows > 0 && (o->strip_world < 1 || o->strip_rank < 0 || o->strip_rank >= o->strip_world)))
         return fail(PT_ERR_INVALID, "strips: rows %d, rank %d of %d", o->strip_rows, o->strip_rank, o->strip_world);
@@ -891,7 +961,32 @@ int pt_set_scene(pt_ctx *c, const pt_static_geom *geoms, int nG, const pt_materi
     }
     c->geoms.assign(geoms, geoms + nG);
     c->mats.assign(mats, mats + nM);
+    c->tri_obj.clear();
+    c->tri_geom.clear();
     c->have_scene = true;
+    c->dirty = true;
+    return PT_OK;
+}
+
+int pt_set_meshes(pt_ctx *c, const pt_mesh *meshes, int n)
+{
+    if (!c || n < 0 || (n > 0 && !meshes)) return fail(PT_ERR_INVALID, "pt_set_meshes: bad arguments (n=%d)", n);
+    if (!c->have_scene) return fail(PT_ERR_INVALID, "pt_set_meshes: call pt_set_scene first");
+    std::vector<float> tri;
+    std::vector<int> owner;
+    for (int k = 0; k < n; ++k) {
+        const pt_mesh &m = meshes[k];
+        if (m.geom < 0 || m.geom >= (int)c->geoms.size() || c->geoms[(size_t)m.geom].type != PT_MESH)
+            return fail(PT_ERR_INVALID, "mesh %d: geom %d is not a MESH object", k, m.geom);
+        if (m.n_triangles < 0 || (m.n_triangles > 0 && !m.vertices)) return fail(PT_ERR_INVALID, "mesh %d: %d triangles, no vertices", k, m.n_triangles);
+        const int mat = c->geoms[(size_t)m.geom].materialid;
+        if (m.n_triangles > 0 && (mat < 0 || mat >= (int)c->mats.size()))
+            return fail(PT_ERR_INVALID, "mesh %d: materialid %d of geom %d outside 0..%d", k, mat, m.geom, (int)c->mats.size() - 1);
+        tri.insert(tri.end(), m.vertices, m.vertices + 9 * (size_t)m.n_triangles);
+        owner.insert(owner.end(), (size_t)m.n_triangles, m.geom);
+    }
+    c->tri_obj.swap(tri);
+    c->tri_geom.swap(owner);
     c->dirty = true;
     return PT_OK;
 }

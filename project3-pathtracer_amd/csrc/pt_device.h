@@ -119,7 +119,7 @@ __device__ __forceinline__ f3 normalize(f3 v)
 // intersection function reads them, ref: src/intersections.h:81-117).
 // ---------------------------------------------------------------------------------------------
 struct Prim {
-    uint32_t type;       // 0 sphere, 1 cube, 2 mesh (never hit)
+    uint32_t type;       // 0 sphere, 1 cube, 2 mesh (never hit: its triangles are records of their own), 3 triangle
     uint32_t material;
     float area;          // surface area when the primitive is a light (direct lighting), else 0
     uint32_t pad1;
@@ -228,12 +228,37 @@ __device__ __forceinline__ f3 pointOnRay(f3 o, f3 d, float t) { return o + (t - 
 // ---------------------------------------------------------------------------------------------
 // RO_GIVEN: `ro` already holds inverseTransform*(origin,1) -- for camera rays it is the same for every lane and
 // is evaluated once per primitive on the host with the same operation order.
-template <bool RO_GIVEN = false>
+// Triangle records (type 2, the flattened MESH geoms): inv[0..8] = v0, e1, e2 in WORLD space, fwd[0..2] = unit normal.
+// Moeller-Trumbore, two-sided, on the ray with its direction normalised first (as the sphere test does); ro = the ray
+// origin, t = distance along rd.  Same operations in the same order as the oracle's o_triangleIntersectionTest.
+__device__ __forceinline__ bool candidateTriangle(const float *w, f3 o, f3 d, f3 &ro, f3 &rd, float &t)
+{
+    ro = o;
+    rd = normalize(d);
+    const f3 v0 = mk(w[0], w[1], w[2]), e1 = mk(w[3], w[4], w[5]), e2 = mk(w[6], w[7], w[8]);
+    const f3 pv = cross(rd, e2);
+    const float det = dot(e1, pv);
+    if (fabsf(det) < 1e-12f) return false;
+    const float inv = rcp_rn(det);
+    const f3 tv = o - v0;
+    const float u = dot(tv, pv) * inv;
+    if (u < 0.0f || u > 1.0f) return false;
+    const f3 qv = cross(tv, e1);
+    const float v = dot(rd, qv) * inv;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    t = dot(e2, qv) * inv;
+    return t > 0.0f;
+}
+
+// TRI: the call site may meet triangle records (type 2); without it type 2 never hits (a MESH geom has no geometry of
+// its own: its triangles are primitives of their own behind the geoms)
+template <bool RO_GIVEN = false, bool TRI = false>
 __device__ __forceinline__ bool candidateT(uint32_t type, const float *inv, f3 o, f3 d, f3 &ro, f3 &rd, float &t,
                                            uint32_t &face)
 {
     face = 0u;
     t = 0.0f;
+    if (TRI && type == 3u) return candidateTriangle(inv, o, d, ro, rd, t);
     if (type > 1u) return false;                         // MESH: parsed by the loader, never has geometry
     if (!RO_GIVEN) ro = mulMV(inv, o, 1.0f);
     rd = normalize(mulMV(inv, d, 0.0f));
@@ -317,14 +342,27 @@ __device__ __forceinline__ f3 boxNormal(const float *fwd, uint32_t face)
 }
 
 // the three stages back to back (direct path: hit work is done inside the wave-uniform primitive loop)
+// a triangle's hit point: getPointOnRay on the normalised world ray, no transform
+__device__ __forceinline__ float hitPointTriangle(f3 o, f3 ro, f3 rd, float t, f3 &real)
+{
+    real = pointOnRay(ro, rd, t);
+    return length(o - real);
+}
+
 template <bool RO_GIVEN = false>
 __device__ __forceinline__ float intersectPrim(const Prim &g, f3 o, f3 d, f3 ro_given, f3 &point, f3 &normal)
 {
     f3 ro = ro_given, rd;
     float t;
     uint32_t face;
-    if (!candidateT<RO_GIVEN>(g.type, g.inv, o, d, ro, rd, t, face)) return -1.0f;
+    if (!candidateT<RO_GIVEN, true>(g.type, g.inv, o, d, ro, rd, t, face)) return -1.0f;
     f3 real;
+    if (g.type == 3u) {
+        const float dist = hitPointTriangle(o, ro, rd, t, real);
+        point = real;
+        normal = mk(g.fwd[0], g.fwd[1], g.fwd[2]);
+        return dist;
+    }
     const float dist = hitPoint(g.fwd, o, ro, rd, t, real);
     point = real;
     if (g.type == 0u) normal = sphereNormal(real, mk(g.cx, g.cy, g.cz));

@@ -65,6 +65,7 @@ struct KParams {
     const float *bvh4;     // the same hierarchy collapsed to 4-wide nodes (GEOM_WALK4), ptd::W4_FLOATS floats per node
     int nnodes4;
     int wdepth;            // its depth in nodes (bounds the traversal stack)
+    int ntri;              // triangle records (type 3) among the nG primitives: the flattened MESH geoms, behind the geoms
     int nbig;              // primitives too large to cull (walls...): tested by every ray before the walk
     int big[16];           // their indices
     const float *face_n;   // per primitive: 8 float4, entry `face code` = world normal of that box face (boxNormal's result)
@@ -98,7 +99,7 @@ struct LaunchCfg {
     int workgroup;   // 64..1024
     int grid;        // workgroups per bounce launch
     int geom;        // 0 scalar direct, 1 LDS direct, 2 hit queue, 3 per-lane hierarchy walk, 4 pair queue, 5 walk + pairs,
-                     // 6 batched 4-wide walk + pairs (pt_kernels.hip)
+                     // 6 batched 4-wide walk + pairs, 7 the same with the nodes in global memory (pt_bounce.h)
     int compact;     // 0 off, 1 per-wave sharded reservation, 2 workgroup scan + single counter
     int nee;         // 1 = explicit light sampling at diffuse vertices (compact must be 1)
     int media;       // 1 = subsurface random walk inside SCATTER materials (compact must be 1, workgroup 256 or 512)

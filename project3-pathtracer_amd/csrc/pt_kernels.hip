@@ -233,8 +233,8 @@ size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg)
     size_t prim = (cfg.geom == GEOM_LDS || cfg.geom == GEOM_QUEUE || cfg.geom == GEOM_PAIR) ? (size_t)p.nG * 2 * sizeof(PrimPad) : 0;
     size_t queue = (size_t)(cfg.workgroup / 64) * (cfg.geom == GEOM_QUEUE ? WAVE_QUEUE_BYTES
                                                    : ((cfg.geom == GEOM_PAIR || cfg.geom == GEOM_WALK_PAIR) ? PAIR_QUEUE_BYTES
-                                                      : (cfg.geom == GEOM_WALK4 ? PAIR_QUEUE_BYTES + WALK4_EXTRA_BYTES : 0)));
-    if (cfg.geom == GEOM_WALK4 && !PT_W4_GLOBAL) prim += ((size_t)p.nnodes4 * W4_FLOATS * 4 + 127) & ~(size_t)127;
+                                                      : ((cfg.geom == GEOM_WALK4 || cfg.geom == GEOM_WALK4G) ? PAIR_QUEUE_BYTES + WALK4_EXTRA_BYTES : 0)));
+    if (cfg.geom == GEOM_WALK4) prim += ((size_t)p.nnodes4 * W4_FLOATS * 4 + 127) & ~(size_t)127;
     if (cfg.geom == GEOM_BVH || cfg.geom == GEOM_WALK_PAIR) prim += (size_t)p.nnodes * sizeof(BvhNode);
     if (cfg.geom == GEOM_PAIR) prim += (size_t)p.nG * 32 * (cfg.nee ? 2 : 1);
     size_t mats = (size_t)((p.nM * M_PLANES + 3) & ~3) * sizeof(float);
@@ -251,6 +251,7 @@ const void *bounce_kernel_g3(int workgroup, bool first, int compact, int feat);
 const void *bounce_kernel_g4(int workgroup, bool first, int compact, int feat);
 const void *bounce_kernel_g5(int workgroup, bool first, int compact, int feat);
 const void *bounce_kernel_g6(int workgroup, bool first, int compact, int feat);
+const void *bounce_kernel_g7(int workgroup, bool first, int compact, int feat);
 
 static const void *select_bounce(const LaunchCfg &cfg, bool first)
 {
@@ -262,6 +263,7 @@ static const void *select_bounce(const LaunchCfg &cfg, bool first)
     case GEOM_PAIR: return bounce_kernel_g4(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1));
     case GEOM_WALK_PAIR: return bounce_kernel_g5(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1));
     case GEOM_WALK4: return bounce_kernel_g6(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1));
+    case GEOM_WALK4G: return bounce_kernel_g7(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1));
     default: return nullptr;
     }
 }

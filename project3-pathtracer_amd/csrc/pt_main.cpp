@@ -156,6 +156,16 @@ int main(int argc, char **argv)
     }
     if (iterOverride >= 0) renderScene->renderCam.iterations = (unsigned)iterOverride;
     bindScene();
+    {
+        // MESH objects: the triangles the loader read from their .obj files go to the renderer beside the call
+        vector<pt_mesh> meshes;
+        for (size_t i = 0; i < renderScene->objects.size(); i++) {
+            const ptamd::geom &o = renderScene->objects[i];
+            if (o.type == PT_MESH && !o.meshVertices.empty())
+                meshes.push_back(pt_mesh{(int)i, (int)(o.meshVertices.size() / 9), o.meshVertices.data()});
+        }
+        if (!meshes.empty()) pt_shim_set_meshes(meshes.data(), (int)meshes.size());
+    }
     if (targetFrame >= renderCam->frames) {
         cout << "Warning: Specified target frame is out of range, defaulting to frame 0." << endl;
         targetFrame = 0;

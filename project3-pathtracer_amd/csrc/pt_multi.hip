@@ -147,6 +147,16 @@ int pt_multi_set_scene(pt_multi *m, const pt_static_geom *geoms, int nG, const p
     return PT_OK;
 }
 
+int pt_multi_set_meshes(pt_multi *m, const pt_mesh *meshes, int n)
+{
+    if (!m) return pt::fail(PT_ERR_INVALID, "pt_multi_set_meshes: invalid argument or state");
+    for (pt_ctx *c : m->ctx) {
+        int rc = pt_set_meshes(c, meshes, n);
+        if (rc != PT_OK) return rc;
+    }
+    return PT_OK;
+}
+
 int pt_multi_set_camera(pt_multi *m, const pt_camera_data *cam)
 {
     if (!m || !cam) return pt::fail(PT_ERR_INVALID, "pt_multi_set_camera: invalid argument or state");

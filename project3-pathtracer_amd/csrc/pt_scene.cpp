@@ -208,8 +208,38 @@ pt_vec2 cameraFov(float fovy, pt_vec2 resolution)
     return {fovx, fovy};
 }
 
+bool loadObjTriangles(const std::string &path, std::vector<float> &out)
+{
+    LineReader f;
+    if (!f.open(path)) return false;
+    std::vector<pt_vec3> verts;
+    std::string line;
+    for (f.next(line); f.more(); f.next(line)) {
+        const std::vector<std::string> t = tokenizeString(line);
+        if (t.empty()) continue;
+        if (t[0] == "v" && t.size() >= 4) {
+            verts.push_back({(float)atof(t[1].c_str()), (float)atof(t[2].c_str()), (float)atof(t[3].c_str())});
+        } else if (t[0] == "f" && t.size() >= 4) {
+            std::vector<long> idx;
+            for (size_t k = 1; k < t.size(); ++k) {
+                long i = atol(t[k].c_str());                 // "a", "a/b", "a//c", "a/b/c": the vertex index comes first
+                if (i < 0) i = (long)verts.size() + i + 1;   // negative: relative to the vertices read so far
+                if (i < 1 || i > (long)verts.size()) { idx.clear(); break; }
+                idx.push_back(i - 1);
+            }
+            for (size_t k = 2; k < idx.size(); ++k) {        // fan around the first vertex
+                const pt_vec3 tri[3] = {verts[(size_t)idx[0]], verts[(size_t)idx[k - 1]], verts[(size_t)idx[k]]};
+                for (const pt_vec3 &v : tri) { out.push_back(v.x); out.push_back(v.y); out.push_back(v.z); }
+            }
+        }
+    }
+    return true;
+}
+
 scene::scene(const std::string &filename, int rotat_units) : rotat_units_(rotat_units)
 {
+    const size_t slash = filename.find_last_of("/\\");
+    dir_ = slash == std::string::npos ? std::string() : filename.substr(0, slash + 1);
     if (!fp_in.open(filename)) {
         errors.push_back("cannot open " + filename);
         return;
@@ -315,8 +345,12 @@ int scene::loadObject(const std::string &objectid)
             std::string name, extension;
             getline(liness, name, '.');
             getline(liness, extension, '.');
-            if (extension == "obj") g.type = PT_MESH;
-            else {
+            if (extension == "obj") {
+                g.type = PT_MESH;
+                g.meshFile = line;
+                if (!loadObjTriangles(dir_ + line, g.meshVertices) && !loadObjTriangles(line, g.meshVertices))
+                    errors.push_back("cannot read mesh " + line + " (the object stays empty)");
+            } else {
                 errors.push_back(line + " is not a valid object type!");
                 return -1;
             }
@@ -406,6 +440,15 @@ int pt_scene_camera_info(const pt_scene *s, unsigned *iterations, char *image_na
         strncpy(image_name, s->s->renderCam.imageName.c_str(), cap - 1);
         image_name[cap - 1] = 0;
     }
+    return PT_OK;
+}
+
+int pt_scene_mesh(const pt_scene *s, int object, const float **vertices_out, int *n_triangles_out)
+{
+    if (!s || !s->s || object < 0 || object >= (int)s->s->objects.size() || !vertices_out || !n_triangles_out) return PT_ERR_INVALID;
+    const ptamd::geom &g = s->s->objects[(size_t)object];
+    *vertices_out = g.meshVertices.empty() ? nullptr : g.meshVertices.data();
+    *n_triangles_out = (int)(g.meshVertices.size() / 9);
     return PT_OK;
 }
 

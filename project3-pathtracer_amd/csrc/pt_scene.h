@@ -17,6 +17,10 @@ struct geom {
     int frames = 0;                 // the reference never initialises this field; here it is the frame count
     std::vector<pt_vec3> translations, rotations, scales;
     std::vector<pt_mat4> transforms, inverseTransforms;
+    // MESH only: the triangles of the .obj file the object names (9 floats each: v0, v1, v2 in object space).  The
+    // reference parses the type and loads nothing (ref: src/scene.cpp:57-66); empty when the file is not found.
+    std::string meshFile;
+    std::vector<float> meshVertices;
 };
 
 // camera, ref: src/sceneStructs.h:50-61
@@ -54,6 +58,7 @@ public:
 private:
     LineReader fp_in;
     int rotat_units_;
+    std::string dir_;               // directory of the scene file: .obj names are relative to it
     int loadMaterial(const std::string &materialid);
     int loadObject(const std::string &objectid);
     int loadCamera();
@@ -63,6 +68,9 @@ private:
 pt_mat4 buildTransformationMatrix(pt_vec3 translation, pt_vec3 rotation, pt_vec3 scale, int rotat_units,
                                   pt_mat4 *inverse_out);
 pt_vec2 cameraFov(float fovy, pt_vec2 resolution);   // ref: src/scene.cpp:204-207
+// Wavefront OBJ: `v x y z` and `f a b c ...` records (1-based or negative indices, a/b/c forms, polygons cut into
+// fans); everything else is skipped.  Appends 9 floats per triangle; false when the file cannot be read.
+bool loadObjTriangles(const std::string &path, std::vector<float> &out);
 
 }  // namespace ptamd
 

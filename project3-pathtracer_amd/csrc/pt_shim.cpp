@@ -55,6 +55,9 @@ struct ShimState {
     int defer = 1;              // PT_SHIM_BATCH / pt_shim_configure: how many iterations may be pending; 1 = render on every call
     bool configured = false;    // pt_shim_configure was called: the environment no longer decides defer / readback_every
     float *last_image = nullptr;   // renderCam->image of the last call (pt_shim_flush copies the image back there)
+    std::vector<std::vector<float>> mesh_vertices;   // pt_shim_set_meshes: copies of the triangles ...
+    std::vector<pt_mesh> meshes;                     // ... and the descriptors pointing into them
+    bool meshes_dirty = false;
 };
 ShimState g;
 
@@ -88,6 +91,19 @@ void pt_shim_configure(int batch, int readback_every)
     g.defer = batch < 1 ? 1 : batch;
     g.readback_every = readback_every < 0 ? 0 : readback_every;
     g.configured = true;
+}
+
+void pt_shim_set_meshes(const pt_mesh *meshes, int n)
+{
+    if (g.ctx) flush_pending();
+    g.mesh_vertices.clear();
+    g.meshes.clear();
+    for (int k = 0; k < n; ++k) {
+        g.mesh_vertices.emplace_back(meshes[k].vertices, meshes[k].vertices + 9 * (size_t)meshes[k].n_triangles);
+        g.meshes.push_back(meshes[k]);
+    }
+    for (size_t k = 0; k < g.meshes.size(); ++k) g.meshes[k].vertices = g.mesh_vertices[k].data();
+    g.meshes_dirty = true;
 }
 
 void pt_shim_flush(void)
@@ -161,6 +177,12 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
         check(pt_multi_set_scene(g.ctx, list.data(), numberOfGeoms, mats.data(), numberOfMaterials), "pt_set_scene");
         g.geoms = list;
         g.mats = mats;
+        g.meshes_dirty = !g.meshes.empty();    // pt_set_scene drops the triangles of the previous scene
+    }
+    if (g.meshes_dirty) {
+        flush_pending();
+        check(pt_multi_set_meshes(g.ctx, g.meshes.data(), (int)g.meshes.size()), "pt_set_meshes");
+        g.meshes_dirty = false;
     }
 
     // package camera (ref: src/raytraceKernel.cu:141-146)

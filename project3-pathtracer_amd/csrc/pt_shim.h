@@ -11,3 +11,8 @@ void pt_shim_configure(int batch, int readback_every);
 // Render whatever is still pending, copy the image into the renderCam->image of the last call, synchronize.
 // Needed only after opting in to deferral, when the caller stops before the scene's last iteration.
 void pt_shim_flush(void);
+// The reference's geom struct has no room for a mesh (ref: src/sceneStructs.h:21-30; its loader reads the .obj name and
+// nothing else), so triangles reach the renderer beside the call: n meshes as pt_mesh of include/pt_abi.h (copied).
+// They stay attached across cudaRaytraceCore calls until replaced.
+struct pt_mesh;
+void pt_shim_set_meshes(const pt_mesh *meshes, int n);

@@ -53,6 +53,13 @@ def main():
         if rng.random() < 0.3:
             opts["lens_radius"] = float(np.float32(rng.uniform(0.05, 0.6)))
             opts["focal_distance"] = float(np.float32(rng.uniform(2, 12)))
+        meshes = None
+        if rng.random() < 0.2:
+            # a MESH object with a handful of random triangles (object space), placed like any other object
+            nt = int(rng.integers(1, 40))
+            geoms.append(O.make_geom(O.MESH, int(rng.integers(0, 4)), rng.uniform(-4, 4, 3), rng.uniform(-3.2, 3.2, 3), rng.uniform(0.5, 4.0, 3)))
+            meshes = {len(geoms) - 1: rng.uniform(-0.5, 0.5, (nt, 9)).astype(np.float32)}
+            gopts["geom_path"] = int(rng.choice([0, 1, 7, 8]))
         strip = None
         if rng.random() < 0.3 and H >= 4:
             world = int(rng.integers(2, 4))
@@ -63,7 +70,7 @@ def main():
         ma = (O.Material * len(mats))(*mats)
         cam = O.make_camera(W, H, eye, view, up, fovy)
         sh = []
-        ref, live = O.render(ga, len(geoms), ma, len(mats), cam, depth, iters=iters, shadow_out=sh, **opts)
+        ref, live = O.render(ga, len(geoms), ma, len(mats), cam, depth, iters=iters, shadow_out=sh, meshes=meshes, **opts)
         if strip is None and rng.random() < 0.25 and H >= 4:
             # the single-process multi-device handle (several contexts on device 0): bands or strips, host gather
             ndev = int(rng.integers(1, 5))
@@ -79,11 +86,15 @@ def main():
                     o.depth = depth
                     for k, v in dict(opts, **gopts).items():
                         setattr(o, k, v)
-                    if gopts["geom_path"] in (2, 3, 5) and n_prims > 200:
+                    if gopts["geom_path"] in (2, 3, 5) and n_prims > 200 and not meshes:
                         o.geom_path = 0
                     assert L.pt_multi_set_options(m, C.byref(o)) == 0, L.pt_last_error()
                     assert L.pt_multi_set_strips(m, srows) == 0
                     assert L.pt_multi_set_scene(m, C.cast(ga, C.POINTER(pkg.StaticGeom)), len(geoms), C.cast(ma, C.POINTER(pkg.Material)), len(mats)) == 0
+                    if meshes:
+                        (gi, tv), = meshes.items()
+                        md = (pkg.Mesh * 1)(pkg.Mesh(gi, tv.shape[0], tv.ctypes.data_as(C.POINTER(C.c_float))))
+                        assert L.pt_multi_set_meshes(m, md, 1) == 0, L.pt_last_error()
                     assert L.pt_multi_set_camera(m, C.cast(C.byref(cam), C.POINTER(pkg.CameraData))) == 0
                     assert L.pt_multi_clear_image(m) == 0
                     assert L.pt_multi_render(m, 1, iters) == 0, L.pt_last_error()
@@ -105,6 +116,8 @@ def main():
                 so = dict(strip_rows=strip[0], strip_world=strip[1], strip_rank=strip[2]) if strip else {}
                 r.set_options(depth=depth, **opts, **gopts, **so)
                 r.set_scene(C.cast(ga, C.POINTER(pkg.StaticGeom)), len(geoms), C.cast(ma, C.POINTER(pkg.Material)), len(mats))
+                if meshes:
+                    r.set_meshes(meshes)
                 r.set_camera(pkg.CameraData.from_buffer_copy(cam))
                 r.clear_image()
                 r.render(1, iters)

@@ -40,6 +40,12 @@ def run(case, override):
     if rng.random() < 0.3:
         opts["lens_radius"] = float(np.float32(rng.uniform(0.05, 0.6)))
         opts["focal_distance"] = float(np.float32(rng.uniform(2, 12)))
+    meshes = None
+    if rng.random() < 0.2:
+        nt = int(rng.integers(1, 40))
+        geoms.append(O.make_geom(O.MESH, int(rng.integers(0, 4)), rng.uniform(-4, 4, 3), rng.uniform(-3.2, 3.2, 3), rng.uniform(0.5, 4.0, 3)))
+        meshes = {len(geoms) - 1: rng.uniform(-0.5, 0.5, (nt, 9)).astype(np.float32)}
+        gopts["geom_path"] = int(rng.choice([0, 1, 7, 8]))
     for k, v in override.items():
         if k in ("geom_path", "batch"):
             gopts[k] = v
@@ -55,10 +61,12 @@ def run(case, override):
     ma = (O.Material * len(mats))(*mats)
     cam = O.make_camera(W, H, eye, view, up, fovy)
     sh = []
-    ref, live = O.render(ga, len(geoms), ma, len(mats), cam, depth, iters=iters, shadow_out=sh, **opts)
+    ref, live = O.render(ga, len(geoms), ma, len(mats), cam, depth, iters=iters, shadow_out=sh, meshes=meshes, **opts)
     with pkg.Renderer(0) as r:
         r.set_options(depth=depth, **opts, **gopts)
         r.set_scene(C.cast(ga, C.POINTER(pkg.StaticGeom)), len(geoms), C.cast(ma, C.POINTER(pkg.Material)), len(mats))
+        if meshes:
+            r.set_meshes(meshes)
         r.set_camera(pkg.CameraData.from_buffer_copy(cam))
         r.clear_image()
         r.render(1, iters)

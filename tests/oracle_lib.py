@@ -69,6 +69,15 @@ class ScatterProps(C.Structure):       # AbsorptionAndScatteringProperties, ref:
     _fields_ = [("absorptionCoefficient", Vec3), ("reducedScatteringCoefficient", C.c_float)]
 
 
+class OMesh(C.Structure):           # o_mesh
+    _fields_ = [("geom", C.c_int), ("n_triangles", C.c_int), ("vertices", C.POINTER(C.c_float))]
+
+
+class Extras(C.Structure):          # o_extras
+    _fields_ = [("n_meshes", C.c_int), ("meshes", C.POINTER(OMesh)), ("n_slices", C.c_int),
+                ("slice_geoms", C.POINTER(StaticGeom)), ("slice_cams", C.POINTER(CameraData))]
+
+
 class Scene(C.Structure):
     _fields_ = [("n_objects", C.c_int), ("n_materials", C.c_int), ("n_frames_camera", C.c_int),
                 ("objects", C.POINTER(StaticGeom)), ("materials", C.POINTER(Material)),
@@ -132,6 +141,13 @@ def lib():
         "o_calculateTransmission": (Vec3, [Vec3, f]),
         "o_sampleLight": (None, [P(StaticGeom), f, P(Vec3), P(Vec3)]),
         "o_log_poly": (f, [f]),
+        "o_triangleIntersectionTest": (f, [Vec3, Vec3, Vec3, Vec3, Ray, P(Vec3), P(Vec3)]),
+        "o_triangleToWorld": (None, [P(StaticGeom), P(f), P(f)]),
+        "o_render_ex": (i, [P(StaticGeom), i, P(Material), i, P(CameraData), P(Options), P(Extras), C.c_void_p, i, i,
+                            C.c_void_p, P(C.c_ulonglong), i]),
+        "o_trace_path_ex": (Vec3, [P(StaticGeom), i, P(Material), i, P(CameraData), P(Options), P(Extras), i, i, u, P(i)]),
+        "o_load_obj": (i, [C.c_char_p, P(P(f)), P(i)]),
+        "o_free_obj": (None, [P(f)]),
         "o_calculateScatterAndAbsorption": (i, [P(Ray), P(f), P(ScatterProps), P(Vec3), P(Material), f, f, f]),
         "o_trace_path": (Vec3, [P(StaticGeom), i, P(Material), i, P(CameraData), P(Options), i, i, u, P(i)]),
         "o_buildTransformationMatrix": (Mat4, [Vec3, Vec3, Vec3, i, P(Mat4)]),
@@ -215,6 +231,21 @@ class LoadedScene:
         self.image_name = s.image_name.decode()
         self.n_frames_camera = s.n_frames_camera
         lib().o_scene_free(C.byref(s))
+        # MESH objects: the oracle's own OBJ reader on the file the object names (relative to the scene file);
+        # {object index: float32 [n, 9]} in object space
+        self.meshes = {}
+        blocks = open(path).read().replace("\r\n", "\n").replace("\r", "\n").split("\n")
+        for k, ln in enumerate(blocks):
+            tok = ln.split()
+            if len(tok) == 2 and tok[0] == "OBJECT" and k + 1 < len(blocks) and blocks[k + 1].strip().endswith(".obj"):
+                vp, nt = C.POINTER(C.c_float)(), C.c_int()
+                name = blocks[k + 1].strip()
+                for cand in (os.path.join(os.path.dirname(path), name), name):
+                    if lib().o_load_obj(cand.encode(), C.byref(vp), C.byref(nt)) == 0:
+                        if nt.value > 0:
+                            self.meshes[int(tok[1])] = np.ctypeslib.as_array(vp, shape=(nt.value, 9)).astype(np.float32).copy()
+                        lib().o_free_obj(vp)
+                        break
 
     def set_resolution(self, w, h):
         """RES override; fov.x recomputed exactly as the loader does (ref: src/scene.cpp:204-207)."""
@@ -223,9 +254,34 @@ class LoadedScene:
         self.camera = c
 
 
+def make_extras(meshes=None, slice_geoms=None, slice_cams=None, nG=0):
+    """o_extras from {geom index: [n, 9] float32 array} and / or motion slices (a list of StaticGeom arrays of nG entries
+    each, optionally a list of CameraData).  Returns (Extras, keep-alive list)."""
+    ex, keep = Extras(), []
+    if meshes:
+        arrs = [(int(g), np.ascontiguousarray(v, dtype=np.float32).reshape(-1, 9)) for g, v in sorted(meshes.items())]
+        desc = (OMesh * len(arrs))()
+        for k, (g, v) in enumerate(arrs):
+            desc[k] = OMesh(g, v.shape[0], v.ctypes.data_as(C.POINTER(C.c_float)))
+        ex.n_meshes, ex.meshes = len(arrs), desc
+        keep += [arrs, desc]
+    if slice_geoms:
+        flat = (StaticGeom * (len(slice_geoms) * nG))()
+        for k, sg in enumerate(slice_geoms):
+            for j in range(nG):
+                flat[k * nG + j] = sg[j]
+        ex.n_slices, ex.slice_geoms = len(slice_geoms), flat
+        keep.append(flat)
+        if slice_cams:
+            cams = (CameraData * len(slice_cams))(*slice_cams)
+            ex.slice_cams = cams
+            keep.append(cams)
+    return ex, keep
+
+
 def render(geoms, nG, mats, nM, cam, depth, iters=1, iter_first=1, rr_start=-1, seed=0, trig=TRIG_POLY,
            image=None, nthreads=None, direct_light=0, shadow_out=None, absorption=0, lens_radius=0.0, focal_distance=1.0,
-           scatter=0):
+           scatter=0, meshes=None, slice_geoms=None, slice_cams=None):
     """Returns (image[H,W,3] float32, live_in[depth] uint64); shadow_out (a list) receives the shadow-ray count."""
     W, H = int(cam.resolution.x), int(cam.resolution.y)
     if image is None:
@@ -237,8 +293,10 @@ def render(geoms, nG, mats, nM, cam, depth, iters=1, iter_first=1, rr_start=-1, 
     if nthreads is None:
         nthreads = os.cpu_count() or 1
     shadow = C.c_ulonglong(0)
-    rc = lib().o_render_counted(geoms, nG, mats, nM, C.byref(cam), C.byref(opt), image.ctypes.data, iter_first, iters,
-                                live.ctypes.data, C.byref(shadow), nthreads)
+    ex, keep = make_extras(meshes, slice_geoms, slice_cams, nG)
+    rc = lib().o_render_ex(geoms, nG, mats, nM, C.byref(cam), C.byref(opt), C.byref(ex), image.ctypes.data, iter_first, iters,
+                           live.ctypes.data, C.byref(shadow), nthreads)
+    del keep
     if rc != 0:
         raise RuntimeError(f"o_render failed: {rc}")
     if shadow_out is not None:

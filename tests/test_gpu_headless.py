@@ -133,3 +133,21 @@ def test_headless_writes_png_when_the_scene_asks_for_one(tmp_path):
     ref, _ = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, depth, iters=iters)
     q = np.clip(ref * np.float32(255.0), 0, 255).astype(np.uint8)[:, ::-1, :]
     assert np.array_equal(got, q)
+
+
+def test_headless_driver_renders_mesh_objects(tmp_path):
+    """scene=mesh_cornell.txt through the reference protocol: the loader reads the .obj files, the driver hands the
+    triangles to the binding (pt_shim_set_meshes), cudaRaytraceCore renders them; BMP == oracle."""
+    pkg = load_package()
+    W, H, depth, iters = 72, 64, 5, 3
+    scene = os.path.join(ROOT, "scenes", "mesh_cornell.txt")
+    env = dict(os.environ, PT_DEPTH=str(depth))
+    res = subprocess.run([pkg.HEADLESS_PATH, f"scene={scene}", "frame=0", "rotat=degrees", f"res={W}x{H}", f"iterations={iters}",
+                          f"out={tmp_path}"], env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    got = read_bmp(os.path.join(tmp_path, "mesh.0.bmp"))
+    sc = O.LoadedScene(scene, O.ROTAT_DEGREES)
+    sc.set_resolution(W, H)
+    img, _ = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, depth, iters=iters, meshes=sc.meshes)
+    want = np.clip(img * np.float32(255.0), 0, 255).astype(np.uint8)[:, ::-1, :]      # buffer x -> picture W-1-x
+    assert np.array_equal(got, want)

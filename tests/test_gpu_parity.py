@@ -671,6 +671,67 @@ def test_subsurface_scattering_with_everything_else(pkg):
             r.set_options(scatter=2)
 
 
+# ---------------------------------------------------------------- triangle meshes (MESH objects)
+def mesh_render(pkg, w, h, depth, iters, **opts):
+    sc = pkg.SceneFile(os.path.join(SCENES, "mesh_cornell.txt"), 1)
+    sc.set_resolution(w, h)
+    with pkg.Renderer(0) as r:
+        r.set_options(depth=depth, **opts)
+        r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
+        r.set_meshes(sc.meshes)
+        r.set_camera(sc.camera)
+        r.clear_image()
+        r.render(1, iters)
+        img = r.download_image()
+        st = r.stats()
+    return img, [int(x) for x in st.live_in[:depth]], st
+
+
+@pytest.mark.parametrize("geom_path", [0, 1, 7, 8])
+def test_triangle_meshes_match_oracle(pkg, geom_path):
+    """mesh_cornell.txt: 350 triangles from two .obj files (a diffuse icosphere, a glass gem made of polygons) beside a
+    sphere and a cube; product loader -> pt_set_meshes -> triangle records in the batched walks / the scalar loop ==
+    oracle loader -> o_render_ex, bit for bit."""
+    g, lg, _ = mesh_render(pkg, 112, 96, 9, 3, geom_path=geom_path)
+    osc = O.LoadedScene(os.path.join(SCENES, "mesh_cornell.txt"), 1)
+    osc.set_resolution(112, 96)
+    c, lc = O.render(osc.geoms, osc.n_objects, osc.mats, osc.n_materials, osc.camera, 9, iters=3, meshes=osc.meshes)
+    check(g, c, lg, [int(x) for x in lc], f"triangle meshes geom_path={geom_path}")
+    assert sum(lg) > 0
+
+
+def test_triangle_meshes_with_options_and_errors(pkg):
+    kw = dict(rr_start=2, direct_light=1, absorption=1, batch=4)
+    g, lg, st = mesh_render(pkg, 80, 60, 8, 5, **kw)
+    osc = O.LoadedScene(os.path.join(SCENES, "mesh_cornell.txt"), 1)
+    osc.set_resolution(80, 60)
+    sh = []
+    c, lc = O.render(osc.geoms, osc.n_objects, osc.mats, osc.n_materials, osc.camera, 8, iters=5, meshes=osc.meshes,
+                     rr_start=2, direct_light=1, absorption=1, shadow_out=sh)
+    check(g, c, lg, [int(x) for x in lc], "meshes + rr + direct light + absorption")
+    assert int(st.shadow_rays) == sh[0]
+    sc = pkg.SceneFile(os.path.join(SCENES, "mesh_cornell.txt"), 1)
+    with pkg.Renderer(0) as r:
+        with pytest.raises(pkg.PtError):
+            r.set_meshes(sc.meshes)                       # no scene yet
+        r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
+        with pytest.raises(pkg.PtError):
+            r.set_meshes({0: sc.meshes[5]})               # geom 0 is a cube
+        r.set_meshes(sc.meshes)
+        r.set_camera(sc.camera)
+        r.set_options(depth=4, geom_path=5)
+        with pytest.raises(pkg.PtError):
+            r.render(1, 1)                                # the pair queue does not know triangles
+        r.set_options(depth=4, geom_path=0)
+        r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)      # drops the meshes again
+        r.clear_image()
+        r.render(1, 1)
+        nomesh = r.download_image()
+    sc.set_resolution(int(sc.camera.resolution.x), int(sc.camera.resolution.y))
+    ref, _ = O.render(osc.geoms, osc.n_objects, osc.mats, osc.n_materials, O.LoadedScene(os.path.join(SCENES, "mesh_cornell.txt"), 1).camera, 4, iters=1)
+    assert np.array_equal(nomesh, ref)
+
+
 # ---------------------------------------------------------------- committed golden fixtures
 def _golden_cases():
     import json

@@ -479,3 +479,67 @@ def test_scatter_render_conserves_and_differs(scenes_dir):
     c, _ = O.render(s2.geoms, s2.n_objects, s2.mats, s2.n_materials, s2.camera, 6, iters=1)
     d, _ = O.render(s2.geoms, s2.n_objects, s2.mats, s2.n_materials, s2.camera, 6, iters=1, scatter=1)
     assert np.array_equal(c, d)
+
+
+# ------------------------------------------------------------------ triangles / MESH objects
+def _tri(v0, v1, v2, o, d):
+    L = O.lib()
+    g = O.make_geom(O.MESH, 0, (0, 0, 0), (0, 0, 0), (1, 1, 1))
+    w = (C.c_float * 12)()
+    L.o_triangleToWorld(C.byref(g), (C.c_float * 9)(*(list(v0) + list(v1) + list(v2))), w)
+    p, n = O.Vec3(), O.Vec3()
+    t = L.o_triangleIntersectionTest(O.v3(w[0:3]), O.v3(w[3:6]), O.v3(w[6:9]), O.v3(w[9:12]), O.Ray(O.v3(o), O.v3(d)), C.byref(p), C.byref(n))
+    return t, p.tup(), n.tup()
+
+
+def test_triangle_intersection_closed_forms():
+    """World-space Moeller-Trumbore: distance to the pulled-back point, geometric normal (not flipped), two-sided, edges
+    inside, outside and parallel rays miss, the direction need not be unit length."""
+    A, B, Cc = (0, 0, 0), (2, 0, 0), (0, 2, 0)                        # normal +z
+    t, p, n = _tri(A, B, Cc, (0.5, 0.5, 3), (0, 0, -1))
+    assert abs(t - (3 - 1e-4)) < 1e-6 and abs(p[2] - 1e-4) < 1e-6 and n == (0, 0, 1)
+    t2, p2, n2 = _tri(A, B, Cc, (0.5, 0.5, -3), (0, 0, 5))           # from behind, unnormalised direction
+    assert abs(t2 - (3 - 1e-4)) < 1e-6 and n2 == (0, 0, 1) and abs(p2[2] + 1e-4) < 1e-6
+    assert _tri(A, B, Cc, (1.5, 1.5, 3), (0, 0, -1))[0] == -1        # beyond the hypotenuse
+    assert _tri(A, B, Cc, (-0.1, 0.5, 3), (0, 0, -1))[0] == -1
+    assert _tri(A, B, Cc, (0.5, 0.5, 3), (0, 0, 1))[0] == -1         # pointing away
+    assert _tri(A, B, Cc, (0.5, 0.5, 3), (1, 0, 0))[0] == -1         # parallel to the plane
+    assert _tri(A, B, Cc, (1.0, 0.0, 2), (0, 0, -1))[0] > 0          # on an edge: inside (u, v >= 0 inclusive)
+    assert _tri(A, A, Cc, (0.5, 0.5, 3), (0, 0, -1))[0] == -1        # degenerate triangle never hit
+    # oblique: hit point lies in the plane (up to the pull-back), distance = |o - p|
+    t3, p3, _ = _tri((1, 1, 1), (4, 1, 2), (1, 5, 3), (2, 2, 9), (0.1, 0.05, -1))
+    assert t3 > 0 and abs(math.dist((2, 2, 9), p3) - t3) < 1e-5
+
+
+def test_obj_readers_agree_and_fan_polygons(scenes_dir, tmp_path):
+    """The oracle's OBJ reader and the product's read the same triangles from the bundled meshes; polygons are cut into
+    fans around their first vertex; negative indices count back from the vertices read so far."""
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    a = O.LoadedScene(scenes_dir + "/mesh_cornell.txt", O.ROTAT_DEGREES)
+    b = pkg.SceneFile(scenes_dir + "/mesh_cornell.txt", pkg.ROTAT_DEGREES)
+    assert sorted(a.meshes) == sorted(b.meshes) == [5, 6]
+    assert a.meshes[5].shape == (320, 9) and a.meshes[6].shape == (1 * 6 + 8 * 2 + 8, 9)
+    for k in a.meshes:
+        assert np.array_equal(a.meshes[k], b.meshes[k])
+    assert a.geoms[5].type == O.MESH and b.geoms[5].type == pkg.MESH
+    obj = tmp_path / "quad.obj"
+    obj.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nf 1/1/1 2/2/1 3/3/1 4/4/1\nf -4 -2 -1\nf 1 2 9\n")
+    vp, nt = C.POINTER(C.c_float)(), C.c_int()
+    assert O.lib().o_load_obj(str(obj).encode(), C.byref(vp), C.byref(nt)) == 0 and nt.value == 3
+    tri = np.ctypeslib.as_array(vp, shape=(3, 9)).copy()
+    O.lib().o_free_obj(vp)
+    assert tri[0].tolist() == [0, 0, 0, 1, 0, 0, 1, 1, 0] and tri[1].tolist() == [0, 0, 0, 1, 1, 0, 0, 1, 0]
+    assert tri[2].tolist() == [0, 0, 0, 1, 1, 0, 0, 1, 0]            # -4 -2 -1 -> vertices 1 3 4; the face with index 9 is dropped
+    scene = tmp_path / "s.txt"
+    scene.write_text(open(scenes_dir + "/mesh_cornell.txt").read().replace("meshes/icosphere.obj", "quad.obj").replace("meshes/gem.obj", "quad.obj"))
+    s2 = pkg.SceneFile(str(scene), pkg.ROTAT_DEGREES)
+    assert np.array_equal(s2.meshes[5], tri) and np.array_equal(s2.meshes[6], tri)
+
+
+def test_mesh_render_is_seen(scenes_dir):
+    sc = O.LoadedScene(scenes_dir + "/mesh_cornell.txt", O.ROTAT_DEGREES)
+    sc.set_resolution(48, 48)
+    a, la = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, 5, iters=1)
+    b, lb = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, 5, iters=1, meshes=sc.meshes)
+    assert not np.array_equal(a, b) and np.isfinite(b).all() and int(lb.sum()) > int(la.sum())
