@@ -156,6 +156,18 @@ typedef struct pt_mesh { int geom; int n_triangles; const float *vertices; } pt_
 int  pt_set_meshes(pt_ctx *ctx, const pt_mesh *meshes, int numberOfMeshes);
 int  pt_set_stream(pt_ctx *ctx, void *hip_stream);    /* render on a caller-owned hipStream_t; NULL = own stream */
 
+/* Motion blur (the reference keeps per-frame TRANS / ROTAT / SCALE and camera arrays, ref: src/sceneStructs.h:21-30,50-61,
+ * and lists motion blur among the features to build, README.md:72-81): the shutter stays open from the frame given to
+ * pt_set_scene / pt_set_camera to the NEXT frame given here.  `slices` scene states are built at shutter times
+ * (k + .5)/slices by interpolating translation / rotation / scale (and the camera's position / view / up) component-wise,
+ * matrices rebuilt as the loader does (rotat_units: PT_ROTAT_*); iterations are dealt to the slices in runs of
+ * PT_SLICE_ITERATIONS: iteration i renders slice ((i - 1) / PT_SLICE_ITERATIONS) % slices, so every launch sequence still
+ * sees one static scene and the running mean converges to the time average.  cam_next = NULL: the camera is at rest.
+ * slices <= 1 or geoms_next = NULL turns it off.  Call after pt_set_scene / pt_set_camera (pt_set_scene drops it). */
+#define PT_SLICE_ITERATIONS 16
+int  pt_set_motion(pt_ctx *ctx, const pt_static_geom *geoms_next_frame, const pt_camera_data *cam_next_frame_or_null,
+                   int slices, int rotat_units);
+
 /* ---- framebuffer: fp32 RGB, 12 B/pixel, index = x + y*W (ref: src/raytraceKernel.cu:98), tile rows only.
  *      It always holds the running mean over the iterations rendered so far. ---- */
 size_t pt_image_bytes(pt_ctx *ctx);
@@ -245,6 +257,8 @@ int  pt_multi_set_scene(pt_multi *m, const pt_static_geom *geoms, int numberOfGe
                         const pt_material *materials, int numberOfMaterials);
 int  pt_multi_set_camera(pt_multi *m, const pt_camera_data *cam);
 int  pt_multi_set_meshes(pt_multi *m, const pt_mesh *meshes, int numberOfMeshes);
+int  pt_multi_set_motion(pt_multi *m, const pt_static_geom *geoms_next_frame, const pt_camera_data *cam_next_frame_or_null,
+                         int slices, int rotat_units);
 int  pt_multi_band(const pt_multi *m, int k, int *row_begin, int *row_end);
 int  pt_multi_clear_image(pt_multi *m);
 int  pt_multi_upload_image(pt_multi *m, const float *host_rgb_full_frame);

@@ -412,3 +412,34 @@ int o_load_obj(const char *path, float **vertices_out, int *n_triangles_out)
 }
 
 void o_free_obj(float *vertices) { free(vertices); }
+
+
+/* ------------------------------------------------------------------ */
+/* Motion blur: the scene state at shutter time t in [0,1] between two animation frames of one      */
+/* object (ref: per-frame TRANS / ROTAT / SCALE arrays, src/sceneStructs.h:21-30): translation, rotation and scale  */
+/* interpolated component-wise in fp32 as a + (b - a) * t, matrices rebuilt by buildTransformationMatrix.           */
+/* ------------------------------------------------------------------ */
+static float lerp1(float a, float b, float t) { return a + (b - a) * t; }
+static o_vec3 lerp3(o_vec3 a, o_vec3 b, float t) { o_vec3 r; r.x = lerp1(a.x, b.x, t); r.y = lerp1(a.y, b.y, t); r.z = lerp1(a.z, b.z, t); return r; }
+
+o_staticGeom o_interpolateGeom(const o_staticGeom *a, const o_staticGeom *b, float t, int rotat_units)
+{
+    o_staticGeom g = *a;
+    g.translation = lerp3(a->translation, b->translation, t);
+    g.rotation = lerp3(a->rotation, b->rotation, t);
+    g.scale = lerp3(a->scale, b->scale, t);
+    g.transform = o_buildTransformationMatrix(g.translation, g.rotation, g.scale, rotat_units, &g.inverseTransform);
+    return g;
+}
+
+o_cameraData o_interpolateCamera(const o_cameraData *a, const o_cameraData *b, float t)
+{
+    o_cameraData c = *a;
+    c.position = lerp3(a->position, b->position, t);
+    c.view = lerp3(a->view, b->view, t);
+    c.up = lerp3(a->up, b->up, t);
+    return c;
+}
+
+/* shutter time of slice k of n: the middle of its interval, in fp32 */
+float o_sliceTime(int k, int n) { return ((float)k + 0.5f) / (float)n; }

@@ -124,6 +124,8 @@ def lib():
         "pt_set_scene": (i, [vp, P(StaticGeom), i, P(Material), i]),
         "pt_set_camera": (i, [vp, P(CameraData)]),
         "pt_set_meshes": (i, [vp, P(Mesh), i]),
+        "pt_set_motion": (i, [vp, P(StaticGeom), P(CameraData), i, i]),
+        "pt_multi_set_motion": (i, [vp, P(StaticGeom), P(CameraData), i, i]),
         "pt_multi_set_meshes": (i, [vp, P(Mesh), i]),
         "pt_scene_mesh": (i, [vp, i, P(P(C.c_float)), P(i)]),
         "pt_set_stream": (i, [vp, vp]),
@@ -257,6 +259,12 @@ class Renderer:
         for k, (g, v) in enumerate(arrs):
             desc[k] = Mesh(g, v.shape[0], v.ctypes.data_as(C.POINTER(C.c_float)))
         _check(self.L.pt_set_meshes(self.h, desc, len(arrs)), "pt_set_meshes")
+
+    def set_motion(self, geoms_next, cam_next, slices, rotat_units=ROTAT_RADIANS):
+        """Motion blur from the frame of set_scene / set_camera to the next frame (pt_set_motion); cam_next may be None."""
+        cn = C.byref(CameraData.from_buffer_copy(cam_next)) if cam_next is not None else None
+        gn = C.cast(geoms_next, C.POINTER(StaticGeom)) if geoms_next is not None else None
+        _check(self.L.pt_set_motion(self.h, gn, cn, slices, rotat_units), "pt_set_motion")
 
     def set_camera(self, cam):
         self.cam = CameraData.from_buffer_copy(cam)

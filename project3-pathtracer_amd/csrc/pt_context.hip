@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "pt_internal.h"
+#include "pt_scene.h"
 
 namespace {
 thread_local std::string g_last_error;
@@ -67,6 +68,14 @@ struct pt_ctx {
     // triangles of the MESH geoms (pt_set_meshes), object space: 9 floats each + the geom they belong to
     std::vector<float> tri_obj;
     std::vector<int> tri_geom;
+    // motion blur (pt_set_motion): one child context per shutter slice, all rendering into THIS context's framebuffer
+    // on this context's stream; pt_render hands every run of 16 iterations to the slice it belongs to
+    std::vector<pt_static_geom> geoms_next;
+    pt_camera_data cam_next;
+    bool have_cam_next = false;
+    int motion_slices = 0, motion_rotat = 0;
+    std::vector<pt_ctx *> slice_ctx;
+    bool motion_dirty = false;
 
     // device state
     bool dirty = true;          // scene / camera / options changed since the last configure
@@ -810,6 +819,63 @@ void batch_schedule(int iter_count, int batch, int *n, int *q, int *r)
     *r = iter_count % *n;
 }
 
+// motion blur: scene state of slice k of n = both frames interpolated at shutter time (k + .5)/n, component-wise in fp32
+// as a + (b - a) * t on translation / rotation / scale (and the camera vectors), matrices rebuilt by the loader's
+// buildTransformationMatrix (ref: src/utilities.cpp:74-90)
+float lerp1(float a, float b, float t) { return a + (b - a) * t; }
+pt_vec3 lerp3(pt_vec3 a, pt_vec3 b, float t) { return {lerp1(a.x, b.x, t), lerp1(a.y, b.y, t), lerp1(a.z, b.z, t)}; }
+
+void drop_slices(pt_ctx *c)
+{
+    for (pt_ctx *k : c->slice_ctx) pt_destroy(k);
+    c->slice_ctx.clear();
+}
+
+int build_slices(pt_ctx *c)
+{
+    if (!c->motion_dirty) return PT_OK;
+    drop_slices(c);
+    const int n = c->motion_slices;
+    for (int k = 0; k < n; ++k) {
+        pt_ctx *ch = nullptr;
+        int rc = pt_create(c->device, &ch);
+        if (rc != PT_OK) return rc;
+        c->slice_ctx.push_back(ch);
+        const float t = ((float)k + 0.5f) / (float)n;
+        std::vector<pt_static_geom> g = c->geoms;
+        for (size_t i = 0; i < g.size(); ++i) {
+            const pt_static_geom &a = c->geoms[i], &b = c->geoms_next[i];
+            g[i].translation = lerp3(a.translation, b.translation, t);
+            g[i].rotation = lerp3(a.rotation, b.rotation, t);
+            g[i].scale = lerp3(a.scale, b.scale, t);
+            g[i].transform = ptamd::buildTransformationMatrix(g[i].translation, g[i].rotation, g[i].scale, c->motion_rotat, &g[i].inverseTransform);
+        }
+        pt_camera_data cam = c->cam;
+        if (c->have_cam_next) {
+            cam.position = lerp3(c->cam.position, c->cam_next.position, t);
+            cam.view = lerp3(c->cam.view, c->cam_next.view, t);
+            cam.up = lerp3(c->cam.up, c->cam_next.up, t);
+        }
+        rc = pt_set_options(ch, &c->opt);
+        if (rc == PT_OK) rc = pt_set_scene(ch, g.data(), (int)g.size(), c->mats.data(), (int)c->mats.size());
+        if (rc == PT_OK && !c->tri_geom.empty()) {
+            // the same object-space triangles under the slice's transforms: one pt_mesh per run of triangles of one geom
+            std::vector<pt_mesh> ms;
+            for (size_t a0 = 0; a0 < c->tri_geom.size();) {
+                size_t a1 = a0;
+                while (a1 < c->tri_geom.size() && c->tri_geom[a1] == c->tri_geom[a0]) ++a1;
+                ms.push_back(pt_mesh{c->tri_geom[a0], (int)(a1 - a0), c->tri_obj.data() + 9 * a0});
+                a0 = a1;
+            }
+            rc = pt_set_meshes(ch, ms.data(), (int)ms.size());
+        }
+        if (rc == PT_OK) rc = pt_set_camera(ch, &cam);
+        if (rc != PT_OK) return rc;
+    }
+    c->motion_dirty = false;
+    return PT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -894,6 +960,7 @@ int pt_create(int device, pt_ctx **out)
 void pt_destroy(pt_ctx *c)
 {
     if (!c) return;
+    drop_slices(c);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_graph(c);
@@ -939,6 +1006,7 @@ int pt_set_options(pt_ctx *c, const pt_options *o)
     if (o->scatter && o->compaction != 1) return fail(PT_ERR_INVALID, "scatter needs compaction 1 (got %d)", o->compaction);
     c->opt = *o;
     c->dirty = true;
+    c->motion_dirty = c->motion_slices > 1;
     return PT_OK;
 }
 
@@ -963,6 +1031,9 @@ int pt_set_scene(pt_ctx *c, const pt_static_geom *geoms, int nG, const pt_materi
     c->mats.assign(mats, mats + nM);
     c->tri_obj.clear();
     c->tri_geom.clear();
+    c->geoms_next.clear();                 // motion blur belongs to the scene it was set for
+    c->motion_slices = 0;
+    drop_slices(c);
     c->have_scene = true;
     c->dirty = true;
     return PT_OK;
@@ -988,6 +1059,32 @@ int pt_set_meshes(pt_ctx *c, const pt_mesh *meshes, int n)
     c->tri_obj.swap(tri);
     c->tri_geom.swap(owner);
     c->dirty = true;
+    c->motion_dirty = c->motion_slices > 1;
+    return PT_OK;
+}
+
+int pt_set_motion(pt_ctx *c, const pt_static_geom *geoms_next, const pt_camera_data *cam_next, int slices, int rotat_units)
+{
+    if (!c) return fail(PT_ERR_INVALID, "pt_set_motion: NULL context");
+    if (slices <= 1 || !geoms_next) {                    // motion off
+        c->motion_slices = 0;
+        c->geoms_next.clear();
+        c->have_cam_next = false;
+        drop_slices(c);
+        return PT_OK;
+    }
+    if (!c->have_scene || !c->have_camera) return fail(PT_ERR_INVALID, "pt_set_motion: call pt_set_scene and pt_set_camera first");
+    if (slices > 64) return fail(PT_ERR_INVALID, "pt_set_motion: %d slices (at most 64)", slices);
+    if (rotat_units != PT_ROTAT_RADIANS && rotat_units != PT_ROTAT_DEGREES) return fail(PT_ERR_INVALID, "pt_set_motion: rotat_units %d", rotat_units);
+    for (size_t i = 0; i < c->geoms.size(); ++i)
+        if (geoms_next[i].type != c->geoms[i].type || geoms_next[i].materialid != c->geoms[i].materialid)
+            return fail(PT_ERR_INVALID, "pt_set_motion: object %d changes type or material between the frames", (int)i);
+    c->geoms_next.assign(geoms_next, geoms_next + c->geoms.size());
+    c->have_cam_next = cam_next != nullptr;
+    if (cam_next) c->cam_next = *cam_next;
+    c->motion_slices = slices;
+    c->motion_rotat = rotat_units;
+    c->motion_dirty = true;
     return PT_OK;
 }
 
@@ -999,6 +1096,7 @@ int pt_set_camera(pt_ctx *c, const pt_camera_data *cam)
     c->cam = *cam;
     c->have_camera = true;
     c->dirty = true;
+    c->motion_dirty = c->motion_slices > 1;
     return PT_OK;
 }
 
@@ -1083,6 +1181,26 @@ int pt_render(pt_ctx *c, int iter_first, int iter_count)
     if (rc != PT_OK) return rc;
     if (iter_count == 0) return PT_OK;
     hipStream_t s = c->stream;
+    if (c->motion_slices > 1) {
+        // motion blur: every run of PT_SLICE_ITERATIONS iterations belongs to one shutter slice, rendered by that
+        // slice's context into this context's framebuffer (the running mean is stateless given image and iteration)
+        rc = build_slices(c);
+        if (rc != PT_OK) return rc;
+        for (pt_ctx *ch : c->slice_ctx) {
+            if (ch->d_image_bound != image_ptr(c)) { rc = pt_bind_image(ch, image_ptr(c)); if (rc != PT_OK) return rc; }
+            if (ch->stream != s) { rc = pt_set_stream(ch, (void *)s); if (rc != PT_OK) return rc; }
+        }
+        for (int it = iter_first; it < iter_first + iter_count;) {
+            const int run = (it - 1) / PT_SLICE_ITERATIONS;
+            int end = (run + 1) * PT_SLICE_ITERATIONS + 1;
+            if (end > iter_first + iter_count) end = iter_first + iter_count;
+            rc = pt_render(c->slice_ctx[(size_t)(run % c->motion_slices)], it, end - it);
+            if (rc != PT_OK) return rc;
+            it = end;
+        }
+        c->image_valid = true;
+        return PT_OK;
+    }
 
     if (c->timers.size() >= 1024) { rc = fold_timers(c); if (rc != PT_OK) return rc; }
     hipEvent_t e0, e1;
@@ -1118,6 +1236,7 @@ int pt_render_profiled(pt_ctx *c, int iter_first, int iter_count, double *bounce
 {
     if (!c || !bounce_ms_out) return fail(PT_ERR_INVALID, "pt_render_profiled: NULL argument");
     if (iter_first < 1 || iter_count < 0) return fail(PT_ERR_INVALID, "pt_render_profiled: iterations [%d,+%d)", iter_first, iter_count);
+    if (c->motion_slices > 1) return fail(PT_ERR_INVALID, "pt_render_profiled: not with motion blur (profile a slice's scene instead)");
     int rc = configure(c);
     if (rc != PT_OK) return rc;
     const int depth = c->kp.depth;
@@ -1240,6 +1359,17 @@ int pt_get_stats(pt_ctx *c, pt_stats *out)
                 (double)h.clk[0] / (double)h.clk[1] * 100.0);
     out->bounce_launches = c->bounce_launches;
     out->shadow_rays = h.shadow_rays;
+    for (pt_ctx *ch : c->slice_ctx) {                    // motion blur: the slices did the work
+        pt_stats cs;
+        rc = pt_get_stats(ch, &cs);
+        if (rc != PT_OK) return rc;
+        out->iterations += cs.iterations;
+        out->ray_bounces += cs.ray_bounces;
+        for (int b = 0; b < PT_MAX_DEPTH; ++b) out->live_in[b] += cs.live_in[b];
+        out->gpu_ms += cs.gpu_ms;
+        out->bounce_launches += cs.bounce_launches;
+        out->shadow_rays += cs.shadow_rays;
+    }
     if (getenv("PT_DEBUG_PHASE") && h.dbg[3] && h.dbg[7])
         fprintf(stderr, "[ptamd] shader clocks per chunk (wave latency): bounce 0: load/gen %.0f, nearest hit %.0f, shade+write %.0f; later: %.0f, %.0f, %.0f\n",
                 (double)h.dbg[0] / h.dbg[3], (double)h.dbg[1] / h.dbg[3], (double)h.dbg[2] / h.dbg[3],
@@ -1269,6 +1399,7 @@ int pt_reset_stats(pt_ctx *c)
     HIP_TRY(hipMemset(c->d_state, 0, sizeof(pt::IterState)));
     c->gpu_ms = 0.0;
     c->bounce_launches = 0;
+    for (pt_ctx *ch : c->slice_ctx) { rc = pt_reset_stats(ch); if (rc != PT_OK) return rc; }
     return PT_OK;
 }
 

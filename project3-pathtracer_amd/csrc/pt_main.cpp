@@ -9,6 +9,7 @@
 //   res=WxH                 RES override, fov.x recomputed as the loader does
 //   iterations=N            ITERATIONS override
 //   out=<dir>               directory for the image file (default: current directory)
+//   motion=K                motion blur: K shutter slices between each frame and the next (0 = off)
 // Trace depth, Russian roulette, seed: environment, see pt_shim.cpp.
 #include <stdio.h>
 #include <stdlib.h>
@@ -124,7 +125,7 @@ int main(int argc, char **argv)
 {
     bool loadedScene = false;
     string scenePath;
-    int rotat = PT_ROTAT_RADIANS, resW = 0, resH = 0, iterOverride = -1;
+    int rotat = PT_ROTAT_RADIANS, resW = 0, resH = 0, iterOverride = -1, motion = -1;
     for (int i = 1; i < argc; i++) {
         string header, data;
         istringstream liness(argv[i]);
@@ -136,6 +137,7 @@ int main(int argc, char **argv)
         else if (header == "res") { if (sscanf(data.c_str(), "%dx%d", &resW, &resH) != 2) resW = resH = 0; }
         else if (header == "iterations") iterOverride = atoi(data.c_str());
         else if (header == "out") outDir = data;
+        else if (header == "motion") motion = atoi(data.c_str());
     }
     if (!loadedScene) {
         cout << "Error: scene file needed!" << endl;
@@ -178,6 +180,7 @@ int main(int argc, char **argv)
     // the binding may render iterations in batches and skip the per-call image copy; the environment still overrides.
     pt_shim_configure(getenv("PT_SHIM_BATCH") ? atoi(getenv("PT_SHIM_BATCH")) : 16,
                       getenv("PT_READBACK_EVERY") ? atoi(getenv("PT_READBACK_EVERY")) : 0);
+    pt_shim_set_motion(motion >= 0 ? motion : (getenv("PT_MOTION_SLICES") ? atoi(getenv("PT_MOTION_SLICES")) : 0), rotat);
     const auto t0 = chrono::steady_clock::now();
     long long calls = 0;
     while (runCuda()) calls++;

@@ -157,6 +157,16 @@ int pt_multi_set_meshes(pt_multi *m, const pt_mesh *meshes, int n)
     return PT_OK;
 }
 
+int pt_multi_set_motion(pt_multi *m, const pt_static_geom *geoms_next, const pt_camera_data *cam_next, int slices, int rotat_units)
+{
+    if (!m) return pt::fail(PT_ERR_INVALID, "pt_multi_set_motion: invalid argument or state");
+    for (pt_ctx *c : m->ctx) {
+        int rc = pt_set_motion(c, geoms_next, cam_next, slices, rotat_units);
+        if (rc != PT_OK) return rc;
+    }
+    return PT_OK;
+}
+
 int pt_multi_set_camera(pt_multi *m, const pt_camera_data *cam)
 {
     if (!m || !cam) return pt::fail(PT_ERR_INVALID, "pt_multi_set_camera: invalid argument or state");

@@ -20,6 +20,8 @@
 //                         (pt_multi_*), the bands are gathered into renderCam->image; PBO output then needs 1 device
 //   PT_STRIP_ROWS (8)     with several devices: rows per interleaved strip (device k renders strips k, k+n, ...); 0 = one
 //                         contiguous band per device
+//   PT_MOTION_SLICES (0)  > 1: motion blur over the interval to the next animation frame, that many shutter slices
+//                         (PT_ROTAT_UNITS 0 radians / 1 degrees: the unit of the scene's ROTAT values)
 //   PT_SHIM_BATCH (1)     iterations that may be pending inside the shim before they are rendered together
 //                         (only while nobody can observe them: no PBO, no read-back due); 1 = render every call
 //   PT_READBACK_EVERY (1) copy renderCam->image back every N iterations; 1 = on every call, as the reference does
@@ -58,6 +60,9 @@ struct ShimState {
     std::vector<std::vector<float>> mesh_vertices;   // pt_shim_set_meshes: copies of the triangles ...
     std::vector<pt_mesh> meshes;                     // ... and the descriptors pointing into them
     bool meshes_dirty = false;
+    int motion_slices = -1, motion_rotat = 0;      // -1: take PT_MOTION_SLICES / PT_ROTAT_UNITS at the first call
+    bool motion_dirty = true;
+    int motion_frame = -1;
 };
 ShimState g;
 
@@ -106,6 +111,14 @@ void pt_shim_set_meshes(const pt_mesh *meshes, int n)
     g.meshes_dirty = true;
 }
 
+void pt_shim_set_motion(int slices, int rotat_units)
+{
+    if (g.ctx) flush_pending();
+    g.motion_slices = slices < 0 ? 0 : slices;
+    g.motion_rotat = rotat_units ? 1 : 0;
+    g.motion_dirty = true;
+}
+
 void pt_shim_flush(void)
 {
     if (!g.ctx) return;
@@ -148,6 +161,10 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
         }
         if (g.defer < 1) g.defer = 1;
         if (g.readback_every < 0) g.readback_every = 0;
+        if (g.motion_slices < 0) {
+            g.motion_slices = env_int("PT_MOTION_SLICES", 0);
+            g.motion_rotat = env_int("PT_ROTAT_UNITS", 0) ? 1 : 0;
+        }
     }
 
     // package geometry (ref: src/raytraceKernel.cu:123-134).  geom::frames is never initialised by the
@@ -198,6 +215,30 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
         check(pt_multi_set_camera(g.ctx, &cam), "pt_set_camera");
         g.cam = cam;
         g.have_cam = true;
+    }
+
+    // motion blur: the shutter stays open until the next frame of the caller's arrays, when there is one
+    if (scene_changed || g.motion_dirty || g.motion_frame != frame) {
+        flush_pending();
+        if (g.motion_slices > 1 && frame + 1 < renderCam->frames) {
+            std::vector<pt_static_geom> next = list;
+            for (int i = 0; i < numberOfGeoms; i++) {
+                memcpy(&next[(size_t)i].translation, &geoms[i].translations[frame + 1], sizeof next[0].translation);
+                memcpy(&next[(size_t)i].rotation, &geoms[i].rotations[frame + 1], sizeof next[0].rotation);
+                memcpy(&next[(size_t)i].scale, &geoms[i].scales[frame + 1], sizeof next[0].scale);
+                memcpy(&next[(size_t)i].transform, &geoms[i].transforms[frame + 1], sizeof next[0].transform);
+                memcpy(&next[(size_t)i].inverseTransform, &geoms[i].inverseTransforms[frame + 1], sizeof next[0].inverseTransform);
+            }
+            pt_camera_data cn = cam;
+            memcpy(&cn.position, &renderCam->positions[frame + 1], sizeof cn.position);
+            memcpy(&cn.view, &renderCam->views[frame + 1], sizeof cn.view);
+            memcpy(&cn.up, &renderCam->ups[frame + 1], sizeof cn.up);
+            check(pt_multi_set_motion(g.ctx, next.data(), &cn, g.motion_slices, g.motion_rotat), "pt_set_motion");
+        } else {
+            check(pt_multi_set_motion(g.ctx, nullptr, nullptr, 0, 0), "pt_set_motion");
+        }
+        g.motion_dirty = false;
+        g.motion_frame = frame;
     }
 
     // one iteration.  iterations == 1 restarts the running mean (the old image is not read); a later

@@ -16,3 +16,8 @@ void pt_shim_flush(void);
 // They stay attached across cudaRaytraceCore calls until replaced.
 struct pt_mesh;
 void pt_shim_set_meshes(const pt_mesh *meshes, int n);
+// Motion blur (PT_MOTION_SLICES > 1 in the environment, or slices here): when the scene has a frame after the one being
+// rendered, the shutter stays open from `frame` to `frame + 1` of the caller's per-frame arrays (pt_set_motion).
+// rotat_units: the unit the scene's ROTAT values are in (0 radians = what the reference's loader assumes, 1 degrees),
+// needed to rebuild the in-between matrices.
+void pt_shim_set_motion(int slices, int rotat_units);

@@ -147,6 +147,9 @@ def lib():
                             C.c_void_p, P(C.c_ulonglong), i]),
         "o_trace_path_ex": (Vec3, [P(StaticGeom), i, P(Material), i, P(CameraData), P(Options), P(Extras), i, i, u, P(i)]),
         "o_load_obj": (i, [C.c_char_p, P(P(f)), P(i)]),
+        "o_interpolateGeom": (StaticGeom, [P(StaticGeom), P(StaticGeom), f, i]),
+        "o_interpolateCamera": (CameraData, [P(CameraData), P(CameraData), f]),
+        "o_sliceTime": (f, [i, i]),
         "o_free_obj": (None, [P(f)]),
         "o_calculateScatterAndAbsorption": (i, [P(Ray), P(f), P(ScatterProps), P(Vec3), P(Material), f, f, f]),
         "o_trace_path": (Vec3, [P(StaticGeom), i, P(Material), i, P(CameraData), P(Options), i, i, u, P(i)]),
@@ -277,6 +280,21 @@ def make_extras(meshes=None, slice_geoms=None, slice_cams=None, nG=0):
             ex.slice_cams = cams
             keep.append(cams)
     return ex, keep
+
+
+def motion_slices(geoms_a, geoms_b, nG, cam_a, cam_b, slices, rotat_units=ROTAT_RADIANS):
+    """The `slices` scene states of a shutter interval from frame a to frame b: (list of StaticGeom arrays, list of
+    cameras), interpolated by the oracle's o_interpolateGeom / o_interpolateCamera at o_sliceTime(k, slices)."""
+    L = lib()
+    sg, sc = [], []
+    for k in range(slices):
+        t = L.o_sliceTime(k, slices)
+        arr = (StaticGeom * max(1, nG))()
+        for j in range(nG):
+            arr[j] = L.o_interpolateGeom(C.byref(geoms_a[j]), C.byref(geoms_b[j]), t, rotat_units)
+        sg.append(arr)
+        sc.append(L.o_interpolateCamera(C.byref(cam_a), C.byref(cam_b), t) if cam_b is not None else CameraData.from_buffer_copy(cam_a))
+    return sg, sc
 
 
 def render(geoms, nG, mats, nM, cam, depth, iters=1, iter_first=1, rr_start=-1, seed=0, trig=TRIG_POLY,

@@ -151,3 +151,27 @@ def test_headless_driver_renders_mesh_objects(tmp_path):
     img, _ = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, depth, iters=iters, meshes=sc.meshes)
     want = np.clip(img * np.float32(255.0), 0, 255).astype(np.uint8)[:, ::-1, :]      # buffer x -> picture W-1-x
     assert np.array_equal(got, want)
+
+
+def test_headless_motion_blur(tmp_path):
+    """motion=3: every frame of sampleScene_anim.txt that has a successor is rendered with the shutter open until that
+    successor (three slices); the last frame is static.  Each image == the oracle's."""
+    pkg = load_package()
+    W, H, depth, iters, K = 64, 48, 4, 36, 3
+    scene = os.path.join(ROOT, "scenes", "sampleScene_anim.txt")
+    env = dict(os.environ, PT_DEPTH=str(depth))
+    res = subprocess.run([pkg.HEADLESS_PATH, f"scene={scene}", f"res={W}x{H}", f"iterations={iters}", "rotat=degrees", f"motion={K}",
+                          f"out={tmp_path}"], env=env, capture_output=True, text=True, timeout=180)
+    assert res.returncode == 0, res.stdout + res.stderr
+    for frame in range(3):
+        got = read_bmp(os.path.join(tmp_path, f"anim.{frame}.bmp"))
+        a = O.LoadedScene(scene, O.ROTAT_DEGREES, frame=frame)
+        a.set_resolution(W, H)
+        kw = {}
+        if frame < 2:
+            b = O.LoadedScene(scene, O.ROTAT_DEGREES, frame=frame + 1)
+            sg, sc = O.motion_slices(a.geoms, b.geoms, a.n_objects, a.camera, b.camera, K, O.ROTAT_DEGREES)
+            kw = dict(slice_geoms=sg, slice_cams=sc)
+        img, _ = O.render(a.geoms, a.n_objects, a.mats, a.n_materials, a.camera, depth, iters=iters, **kw)
+        want = np.clip(img * np.float32(255.0), 0, 255).astype(np.uint8)[:, ::-1, :]
+        assert np.array_equal(got, want), frame

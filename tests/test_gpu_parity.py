@@ -732,6 +732,43 @@ def test_triangle_meshes_with_options_and_errors(pkg):
     assert np.array_equal(nomesh, ref)
 
 
+# ---------------------------------------------------------------- motion blur
+@pytest.mark.parametrize("slices,iters,extra", [(4, 40, {}), (2, 33, {"batch": 5, "rr_start": 2}), (3, 50, {"direct_light": 1, "geom_path": 7})])
+def test_motion_blur_matches_oracle(pkg, slices, iters, extra):
+    """pt_set_motion: the shutter open from frame 0 to frame 1 of sampleScene_anim.txt (spheres move, the camera dollies);
+    runs of 16 iterations go to the slice contexts in turn and accumulate in one framebuffer == the oracle's per-iteration
+    scene states."""
+    path = os.path.join(SCENES, "sampleScene_anim.txt")
+    W, H, depth = 96, 72, 5
+    a, b = pkg.SceneFile(path, 1, frame=0), pkg.SceneFile(path, 1, frame=1)
+    a.set_resolution(W, H)
+    with pkg.Renderer(0) as r:
+        r.set_options(depth=depth, **extra)
+        r.set_scene(a.geoms, a.n_objects, a.mats, a.n_materials)
+        r.set_camera(a.camera)
+        r.set_motion(b.geoms, b.camera, slices, pkg.ROTAT_DEGREES)
+        r.clear_image()
+        r.render(1, 7)                                    # in pieces, across slice boundaries
+        r.render(8, iters - 7)
+        g = r.download_image()
+        st = r.stats()
+        r.set_motion(None, None, 0)                       # off again: the static frame
+        r.clear_image()
+        r.render(1, 3)
+        static = r.download_image()
+    oa, ob = O.LoadedScene(path, 1, frame=0), O.LoadedScene(path, 1, frame=1)
+    oa.set_resolution(W, H)
+    sg, sc = O.motion_slices(oa.geoms, ob.geoms, oa.n_objects, oa.camera, ob.camera, slices, O.ROTAT_DEGREES)
+    sh = []
+    okw = {k: v for k, v in extra.items() if k in ("rr_start", "direct_light")}
+    c, lc = O.render(oa.geoms, oa.n_objects, oa.mats, oa.n_materials, oa.camera, depth, iters=iters, slice_geoms=sg, slice_cams=sc,
+                     shadow_out=sh, **okw)
+    check(g, c, [int(x) for x in st.live_in[:depth]], [int(x) for x in lc], f"motion blur {slices} slices")
+    assert int(st.iterations) == iters and int(st.shadow_rays) == sh[0]
+    c0, _ = O.render(oa.geoms, oa.n_objects, oa.mats, oa.n_materials, oa.camera, depth, iters=3, **okw)
+    assert np.array_equal(static, c0) and not np.array_equal(g, c0)
+
+
 # ---------------------------------------------------------------- committed golden fixtures
 def _golden_cases():
     import json

@@ -543,3 +543,32 @@ def test_mesh_render_is_seen(scenes_dir):
     a, la = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, 5, iters=1)
     b, lb = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, 5, iters=1, meshes=sc.meshes)
     assert not np.array_equal(a, b) and np.isfinite(b).all() and int(lb.sum()) > int(la.sum())
+
+
+# ------------------------------------------------------------------ motion blur
+def test_motion_slices_schedule_and_interpolation(scenes_dir):
+    """Slice k of n sits at shutter time (k + .5)/n between the two frames; iterations are dealt to the slices in runs of
+    16; one slice with identical frames is the static render; a moving sphere smears."""
+    L = O.lib()
+    a = O.LoadedScene(scenes_dir + "/sampleScene_anim.txt", O.ROTAT_DEGREES, frame=0)
+    b = O.LoadedScene(scenes_dir + "/sampleScene_anim.txt", O.ROTAT_DEGREES, frame=1)
+    for s in (a, b):
+        s.set_resolution(48, 36)
+    assert [L.o_sliceTime(k, 4) for k in range(4)] == [0.125, 0.375, 0.625, 0.875]
+    g = L.o_interpolateGeom(C.byref(a.geoms[5]), C.byref(b.geoms[5]), 0.5, O.ROTAT_DEGREES)
+    for c in "xyz":
+        want = np.float32(getattr(a.geoms[5].translation, c)) + (np.float32(getattr(b.geoms[5].translation, c)) - np.float32(getattr(a.geoms[5].translation, c))) * np.float32(0.5)
+        assert getattr(g.translation, c) == float(want)
+    same = O.motion_slices(a.geoms, a.geoms, a.n_objects, a.camera, a.camera, 3, O.ROTAT_DEGREES)
+    st, _ = O.render(a.geoms, a.n_objects, a.mats, a.n_materials, a.camera, 4, iters=20)
+    mv, _ = O.render(a.geoms, a.n_objects, a.mats, a.n_materials, a.camera, 4, iters=20, slice_geoms=same[0], slice_cams=same[1])
+    assert np.array_equal(st, mv)                      # nothing moves: the slices are the static scene
+    sg, sc = O.motion_slices(a.geoms, b.geoms, a.n_objects, a.camera, b.camera, 2, O.ROTAT_DEGREES)
+    blur, _ = O.render(a.geoms, a.n_objects, a.mats, a.n_materials, a.camera, 4, iters=32, slice_geoms=sg, slice_cams=sc)
+    # iterations 1..16 see slice 0, 17..32 slice 1: the mean of the two half-renders
+    h0, _ = O.render(sg[0], a.n_objects, a.mats, a.n_materials, sc[0], 4, iters=16)
+    assert not np.array_equal(blur, st)
+    first16, _ = O.render(a.geoms, a.n_objects, a.mats, a.n_materials, a.camera, 4, iters=16, slice_geoms=sg, slice_cams=sc)
+    sc0 = O.CameraData.from_buffer_copy(sc[0]); sc0.resolution = a.camera.resolution; sc0.fov = a.camera.fov
+    h0, _ = O.render(sg[0], a.n_objects, a.mats, a.n_materials, sc0, 4, iters=16)
+    assert np.array_equal(first16, h0)
