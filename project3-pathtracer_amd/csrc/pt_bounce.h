@@ -23,7 +23,9 @@ static constexpr uint32_t DEAD = 0xFFFFFFFFu;
 #endif
 static constexpr bool DEBUG_CULL = false;
 static constexpr bool DEBUG_PAIR = PT_DEBUG_PAIR != 0;
-static constexpr bool DEBUG_PHASE = PT_DEBUG_PHASE != 0;     // per-wave shader-clock stamps between the phases of a chunk -> IterState::dbg
+static constexpr bool DEBUG_PHASE = PT_DEBUG_PHASE == 1;     // per-wave shader-clock stamps between the phases of a chunk -> IterState::dbg
+static constexpr bool DEBUG_PHASE2 = PT_DEBUG_PHASE == 2;    // finer split of the later bounces (pair-queue path): load, pre-test loop
+                                                             // + full batches, last batches, result, RNG, lobe + radiance write, compaction
 static constexpr bool DEBUG_BVH = PT_DEBUG_BVH != 0;         // count node / leaf visits of the hierarchy walk into IterState::dbg
 static constexpr int MAXSLOT = 16;                // iterations in flight per launch sequence (pt_internal.h PT_MAX_BATCH)
 static constexpr uint32_t SLOT_SHIFT = 27;        // pixel word = tile-local pixel | slot << 27 | NEE mark << 31
@@ -58,6 +60,7 @@ struct Hit {
     uint32_t prim;      // index of the primitive hit (used by shadow rays)
     float t;            // world-space distance to the hit
     bool any;
+    unsigned long long dbg0, dbg1;   // DEBUG_PHASE2 builds: shader clocks of the pre-test loop / the last batches (else unused)
 };
 
 // GEOM selects how the primitive list reaches the lanes:
@@ -476,6 +479,7 @@ template <bool FIRST, class PR>
 __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_prims, const float4 *s_boxes, const PairQueue q,
                                                f3 o, f3 d, bool valid, uint32_t lane)
 {
+    const unsigned long long ph_in = (DEBUG_PHASE2 && !FIRST) ? __builtin_amdgcn_s_memtime() : 0ull;
     q.key[lane] = KEY_NONE;
     q.org[lane] = make_float4(o.x, o.y, o.z, d.x);
     q.dir[lane] = make_float2(d.y, d.z);
@@ -521,6 +525,7 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
         atomicAdd(&p.st->dbg[5], (unsigned long long)((tail[0] + 63) / 64 + (tail[1] + 63) / 64));
         atomicAdd(&p.st->dbg[6], 1ull);
     }
+    const unsigned long long ph_a = (DEBUG_PHASE2 && !FIRST) ? __builtin_amdgcn_s_memtime() : 0ull;
     const uint32_t left0 = tail[0] - head[0], left1 = tail[1] - head[1];      // both < 64
     if (left0 != 0u && left1 != 0u && left0 + left1 <= 64u) {
         pairBatch<2u, FIRST>(p, s_prims, q, head[0], left0, lane, head[1], left1);   // one mixed batch instead of two partial ones
@@ -530,6 +535,10 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
     }
     wave_lds_fence();
     Hit h;
+    if (DEBUG_PHASE2 && !FIRST) {
+        h.dbg0 = ph_a - ph_in;
+        h.dbg1 = __builtin_amdgcn_s_memtime() - ph_a;
+    }
     h.any = false;
     h.material = 0;
     h.prim = 0;
@@ -1078,7 +1087,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
     uint32_t live_count = 0;      // COMPACT 0: rays this wave found alive on entry
     uint32_t shadow_count = 0;    // NEE: shadow rays this wave traced
     int round = 0;
-    unsigned long long ph[5] = {0, 0, 0, 0, 0};
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, ph5 = 0, ph6 = 0;
     // pool slot of this lane in the chunk workgroup-round R2 gives this wave, and whether there is a ray in it
     auto locate = [&](Cursor &cu, uint32_t R2, uint32_t &slot_i) -> bool {
         const uint32_t chunk = R2 * NW + wave;
@@ -1093,7 +1102,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
     };
     Cursor cur = {0u, 0u, (uint32_t)__builtin_amdgcn_readfirstlane((int)s_segn[0])};
     for (uint32_t R = blockIdx.x; R * NW < total_chunks; R += gridDim.x, ++round) {     // workgroup-uniform trip count
-        const unsigned long long tc0 = DEBUG_PHASE ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long tc0 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
         uint32_t i;
         bool valid = locate(cur, R, i);
         const bool in_pool = valid;                               // the slot exists (COMPACT 0: it may hold a dead ray)
@@ -1167,11 +1176,11 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
         if (COMPACT == 0) live_count += (uint32_t)__popcll(__ballot(valid));
 
         bool alive = false;
-        const unsigned long long c1 = DEBUG_PHASE ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long c1 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
         // camera rays share the eye (host-side eye transforms and eye-relative boxes) unless a lens spreads their origins
         const Hit h = (FIRST && p.lens_radius > 0.0f) ? nearestHit<GEOM, false>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane)
                                                       : nearestHit<GEOM, FIRST>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane);
-        const unsigned long long c2 = DEBUG_PHASE ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long c2 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
         f3 L = mk(0, 0, 0);               // radiance this vertex adds to the path's sample
         // direct lighting: the shadow ray this lane wants traced and what it is worth if the light is visible
         bool want_shadow = false;
@@ -1370,8 +1379,9 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
             lp[2] = L.z;
         }
 
-        const unsigned long long c3 = DEBUG_PHASE ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long c3 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
         if (DEBUG_PHASE) { ph[0] += c1 - tc0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[4] += 1; }
+        if (DEBUG_PHASE2 && !FIRST) { ph[0] += c1 - tc0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[4] += 1; ph5 += h.dbg0; ph6 += h.dbg1; }
         if (last) continue;      // wave-uniform: nothing survives the last bounce
 
         if (COMPACT != 0) {
@@ -1420,12 +1430,22 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                 }
             }
         }
+        if (DEBUG_PHASE2 && !FIRST) ph[3] += __builtin_amdgcn_s_memtime() - c3;
     }
     if (COMPACT == 0) {
         if (lane == 0 && live_count) atomicAdd(&st->counts[cnt_index(bounce, 0)], live_count);
     }
     if (NEE) {
         if (lane == 0 && shadow_count) atomicAdd(&st->shadow_rays, (unsigned long long)shadow_count);
+    }
+    if (DEBUG_PHASE2 && !FIRST && lane == 0) {
+        atomicAdd(&st->dbg[1], ph5);
+        atomicAdd(&st->dbg[2], ph6);
+        atomicAdd(&st->dbg[0], ph[0]);       // load
+        atomicAdd(&st->dbg[3], ph[1]);       // whole nearest hit (dbg[1], dbg[2] = its first two parts)
+        atomicAdd(&st->dbg[4], ph[2]);       // shading + radiance write
+        atomicAdd(&st->dbg[5], ph[3]);       // compaction + pool write
+        atomicAdd(&st->dbg[7], ph[4]);
     }
     if (DEBUG_PHASE && lane == 0) {
         const int base = FIRST ? 0 : 4;
