@@ -1200,15 +1200,9 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                     // calculateBSDF: pick the lobe, build the next ray
                     const uint32_t slot = NEE ? ((pix >> SLOT_SHIFT) & (uint32_t)(MAXSLOT - 1)) : (pix >> SLOT_SHIFT);
                     const uint32_t kb = s_key[slot];
-                    uint32_t s = minstd_seed(wang_hash(globalPixel(p, pix & PIX_MASK) ^ kb));
-                    s = minstd_next(s);
-                    const float u_select = u01_of(s);
-                    s = minstd_next(s);
-                    const float xi1 = u01_of(s);
-                    s = minstd_next(s);
-                    const float xi2 = u01_of(s);
-                    s = minstd_next(s);
-                    const float u_rr = u01_of(s);
+                    // the bounce's draws in stream order u_select, xi1, xi2, u_rr, then (light sampling) u_light, u_seed or
+                    // (inside a medium) u_sd, u_s2, u_s3: each by its own jump from the seed, computed where it is used
+                    const uint32_t s0 = minstd_seed(wang_hash(globalPixel(p, pix & PIX_MASK) ^ kb));
 
                     const float ndotd = dot(h.n, d);
                     const bool backside = ndotd > 0.0f;
@@ -1221,10 +1215,8 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                     if (NEE && diffuse) {
                         // one light, one point on it (the reference's float-seeded samplers), one shadow ray;
                         // estimator T*c/pi * Le * cos_x cos_y / d^2 * (area * number of lights)
-                        s = minstd_next(s);
-                        const float u_light = u01_of(s);
-                        s = minstd_next(s);
-                        const float u_seed = u01_of(s);
+                        const float u_light = u01_of(minstd_jump(s0, MINSTD_A5));
+                        const float u_seed = u01_of(minstd_jump(s0, MINSTD_A6));
                         int j = (int)(u_light * (float)p.nlights);
                         if (j > p.nlights - 1) j = p.nlights - 1;
                         lprim = (uint32_t)p.lights[j];
@@ -1266,12 +1258,9 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                         if (backside) {
                             // the segment ran through the medium: three more draws of the bounce's stream decide whether
                             // the path scatters before the boundary or reaches it (calculateScatterAndAbsorption)
-                            s = minstd_next(s);
-                            const float u_sd = u01_of(s);
-                            s = minstd_next(s);
-                            const float u_s2 = u01_of(s);
-                            s = minstd_next(s);
-                            const float u_s3 = u01_of(s);
+                            const float u_sd = u01_of(minstd_jump(s0, MINSTD_A5));
+                            const float u_s2 = u01_of(minstd_jump(s0, MINSTD_A6));
+                            const float u_s3 = u01_of(minstd_jump(s0, MINSTD_A7));
                             const f3 sa = mk(s_mats[M_AR * p.nM + m], s_mats[M_AG * p.nM + m], s_mats[M_AB * p.nM + m]);
                             f3 mo = o, md = d;
                             float seg = h.t;
@@ -1309,7 +1298,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                             if (sa.x != 0.0f || sa.y != 0.0f || sa.z != 0.0f) T = T * calculateTransmission(sa, h.t);
                         }
                         T = T * mk(s_mats[M_SR * p.nM + m], s_mats[M_SG * p.nM + m], s_mats[M_SB * p.nM + m]);
-                        if (u_select < Rf) nd = rdir;
+                        if (u01_of(minstd_jump(s0, MINSTD_A1)) < Rf) nd = rdir;      // u_select
                         else {
                             // transmitted: start beyond the surface.  h.p was pulled back by getPointOnRay's 1e-4
                             // object-space epsilon (ref: src/intersections.h:46-48) = 1e-4/|inverseTransform*d| in
@@ -1328,7 +1317,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                         nd = reflectionDirection(nf, d);
                     } else {
                         T = T * mk(s_mats[M_CR * p.nM + m], s_mats[M_CG * p.nM + m], s_mats[M_CB * p.nM + m]);
-                        nd = randomDirectionInHemisphere(nf, xi1, xi2);
+                        nd = randomDirectionInHemisphere(nf, u01_of(minstd_jump(s0, MINSTD_A2)), u01_of(minstd_jump(s0, MINSTD_A3)));   // xi1, xi2
                     }
                     if (!scattered) o = h.p + bias * bias_n;
                     d = nd;
@@ -1338,7 +1327,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                         if (T.y > q) q = T.y;
                         if (T.z > q) q = T.z;
                         q = (q < 0.05f) ? 0.05f : ((q > 1.0f) ? 1.0f : q);
-                        if (u_rr >= q) alive = false;
+                        if (u01_of(minstd_jump(s0, MINSTD_A4)) >= q) alive = false;      // u_rr
                         else T = mk(T.x / q, T.y / q, T.z / q);
                     }
                     if (NEE) pix = (pix & 0x7FFFFFFFu) | (diffuse ? 0x80000000u : 0u);

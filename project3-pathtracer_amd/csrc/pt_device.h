@@ -184,6 +184,20 @@ __device__ __forceinline__ uint32_t minstd_next(uint32_t x)
     const uint32_t w = r - m;                  // r < 2m: the reduced value is the smaller of r and r - m as unsigned
     return w < r ? w : r;                      // (v_min_u32 instead of a compare + select)
 }
+// k steps of the engine at once: x * 48271^k mod (2^31 - 1), with 48271^k reduced on the host side of this header
+// (MINSTD_A[k-1]).  The product of two values below 2^31 fits 62 bits, so the same fold applies.  The draws of a
+// bounce are then independent of each other: a lobe that needs only xi1, xi2 does not run the engine through u_select,
+// and the chain of dependent 64-bit multiplies is gone.  Values are those of k successive minstd_next calls.
+__device__ __forceinline__ uint32_t minstd_jump(uint32_t x, uint32_t a_pow_k)
+{
+    const uint32_t m = 2147483647u;
+    const uint64_t p = (uint64_t)x * a_pow_k;
+    const uint32_t r = (uint32_t)(p & m) + (uint32_t)(p >> 31);      // < 2m
+    const uint32_t w = r - m;
+    return w < r ? w : r;
+}
+static constexpr uint32_t MINSTD_A1 = 48271u, MINSTD_A2 = 182605794u, MINSTD_A3 = 1291394886u, MINSTD_A4 = 1914720637u,
+                          MINSTD_A5 = 2078669041u, MINSTD_A6 = 407355683u, MINSTD_A7 = 1105902161u;   // 48271^k mod (2^31 - 1)
 __device__ __forceinline__ float u01_of(uint32_t x) { return (float)(x - 1u) / 2147483648.0f; }
 
 // ---------------------------------------------------------------------------------------------
