@@ -752,7 +752,8 @@ __device__ __forceinline__ Hit nearestHitWalkPairs(const KParams &p, const Prim 
 // GEOM_WALK4
 // ---------------------------------------------------------------------------------------------------------------
 static constexpr uint32_t W4_STACK = 384;                              // traversal entries per wave
-static constexpr uint32_t WALK4_EXTRA_BYTES = 64 * 32 + W4_STACK * 4 + QCAP * 4;  // per wave, behind the pair queue: ray reciprocals, stack, triangle queue
+// per wave: the pair queue, then ray reciprocals, the entry ring and -- only when the scene has triangles -- their queue
+__host__ __device__ constexpr uint32_t walk4_wave_bytes(int ntri) { return PAIR_QUEUE_BYTES + 64 * 32 + W4_STACK * 4 + (ntri > 0 ? QCAP * 4 : 0); }
 struct Walk4 {
     const unsigned char *nodes;   // LDS copy of the 4-wide hierarchy (ptd::W4_FLOATS floats per node)
     float4 *inv;                  // [64][2] per owner lane: (1/d.xyz, -o.x/d.x) (-o.y/d.y, -o.z/d.z, near-plane byte offsets, 0)
@@ -818,18 +819,27 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
         if (valid) w.stack[rank] = lane;                      // owner | node 0
         top = (uint32_t)__popcll(vm);
     }
-    // A popped entry leaves at most 4 behind (net +3).  Batches only run while the stack keeps 3*depth + 4 entries in
-    // reserve; when it does not, entries are popped one at a time -- plain depth-first order, which needs no more than
-    // that reserve above the point it started from.
+    // The entries live in a ring (a deque): pushes go to its tail; a step pops its nb oldest entries from the HEAD while
+    // the ring has room for a full batch's children -- generation by generation, so the steps stay full (the rays of a
+    // chunk descend the hierarchy level by level: 10.8 -> 9.x steps per round on the 256-primitive cloud) -- and its nb
+    // newest from the TAIL when it has not: depth-first order, whose growth is bounded.  A popped entry leaves at most 4
+    // behind (net +3): tail batches only run while 3*depth + 4 entries stay in reserve, below that entries are popped
+    // one at a time, and plain depth-first descent needs no more than that reserve above the point it started from.
     const int reserve = 3 * p.wdepth + 4;
+    uint32_t qh = 0u;                                         // ring index of the oldest entry (wave-uniform)
     uint32_t dbg_steps = 0, dbg_entries = 0;
-    while (top != 0u) {
-        int room = ((int)W4_STACK - reserve - (int)top) / 3;
+    auto wrap = [](uint32_t x) -> uint32_t { const uint32_t y = x - W4_STACK; return y < x ? y : x; };   // x < 2 * W4_STACK
+    while (top != 0u) {                                       // top = entries in the ring
+        const bool fifo = (int)top + 3 * 64 <= (int)W4_STACK - reserve;
         uint32_t nb = top < 64u ? top : 64u;
-        if (room < (int)nb) nb = room < 1 ? 1u : (uint32_t)room;
+        if (!fifo) {
+            const int room = ((int)W4_STACK - reserve - (int)top) / 3;
+            if (room < (int)nb) nb = room < 1 ? 1u : (uint32_t)room;
+        }
         wave_lds_fence();
         const bool act = lane < nb;
-        const uint32_t e = act ? w.stack[top - 1u - lane] : 0u;
+        const uint32_t e = act ? w.stack[wrap(fifo ? qh + lane : qh + top - 1u - lane)] : 0u;
+        if (fifo) qh = wrap(qh + nb);
         top -= nb;
         if (DEBUG_BVH) { dbg_steps++; dbg_entries += nb; }
         const bool leaf = act && (e >> 31) != 0u;
@@ -869,7 +879,7 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
             if (mask == 0ull) continue;
             const bool pass = __builtin_amdgcn_inverse_ballot_w64(mask);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            if (pass) w.stack[top + rank] = owner | cha[c];
+            if (pass) w.stack[wrap(wrap(qh + top) + rank)] = owner | cha[c];
             top += (uint32_t)__popcll(mask);
         }
     }
@@ -993,9 +1003,9 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                            : (GEOM == GEOM_WALK4 ? ((p.nnodes4 * W4_FLOATS * 4 + 127) & ~127)
                                                  : (GEOM == GEOM_PAIR ? p.nG * 32 * (NEE ? 2 : 1) : 0));
     unsigned char *s_queue = smem + prim_bytes + node_bytes;
-    constexpr int WAVE_LDS = (GEOM == GEOM_QUEUE) ? (int)WAVE_QUEUE_BYTES
-                             : ((GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR) ? (int)PAIR_QUEUE_BYTES
-                                : ((GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) ? (int)(PAIR_QUEUE_BYTES + WALK4_EXTRA_BYTES) : 0));
+    const int WAVE_LDS = (GEOM == GEOM_QUEUE) ? (int)WAVE_QUEUE_BYTES
+                         : ((GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR) ? (int)PAIR_QUEUE_BYTES
+                            : ((GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) ? (int)walk4_wave_bytes(p.ntri) : 0));
     const int queue_bytes = NW * WAVE_LDS;
     float *s_mats = reinterpret_cast<float *>(s_queue + queue_bytes);
     const int mat_words = (p.nM * M_PLANES + 3) & ~3;
