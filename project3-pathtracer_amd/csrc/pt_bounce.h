@@ -21,6 +21,10 @@ static constexpr uint32_t DEAD = 0xFFFFFFFFu;
 #ifndef PT_DEBUG_BVH
 #define PT_DEBUG_BVH 0
 #endif
+#ifndef PT_DEBUG_BOUNDS
+#define PT_DEBUG_BOUNDS 0
+#endif
+static constexpr bool DEBUG_BOUNDS = PT_DEBUG_BOUNDS != 0;   // index checks before global accesses; first violation -> IterState::dbg
 static constexpr bool DEBUG_CULL = false;
 static constexpr bool DEBUG_PAIR = PT_DEBUG_PAIR != 0;
 static constexpr bool DEBUG_PHASE = PT_DEBUG_PHASE == 1;     // per-wave shader-clock stamps between the phases of a chunk -> IterState::dbg
@@ -32,6 +36,15 @@ static constexpr uint32_t SLOT_SHIFT = 27;        // pixel word = tile-local pix
 static constexpr uint32_t PIX_MASK = (1u << SLOT_SHIFT) - 1u;
 
 typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
+
+// diagnostic builds (-DPT_DEBUG_BOUNDS=1, PT_DEBUG_BOUNDS=1 at run time prints it): report the first out-of-range index
+// (code, value, limit) in IterState::dbg and let the caller make the access harmless
+__device__ __forceinline__ bool dbgInRange(const KParams &p, int code, unsigned long long v, unsigned long long lim)
+{
+    if (!DEBUG_BOUNDS || v < lim) return true;
+    if (atomicCAS(&p.st->dbg[0], 0ull, (unsigned long long)code) == 0ull) { p.st->dbg[1] = v; p.st->dbg[2] = lim; p.st->dbg[4] = blockIdx.x; p.st->dbg[5] = threadIdx.x; }
+    return false;
+}
 
 // Wave-uniform primitive fetch through the constant address space: hipcc turns this into s_load_dwordx16 x2
 // and keeps the record in SGPRs.
@@ -437,7 +450,8 @@ __device__ __forceinline__ void pairBatch(const KParams &p, const PR *s_prims, c
                            : ((TYPE == 2u && lane >= nb) ? q.q[1][(head2 + lane - nb) & (QCAP - 1u)]
                                                          : q.q[(TYPE == 2u || TYPE == 3u) ? 0u : TYPE][(head + lane) & (QCAP - 1u)]);
         owner = e & 63u;
-        const uint32_t prim = e >> 8;
+        uint32_t prim = e >> 8;
+        if (!dbgInRange(p, 10 + (int)TYPE, prim, (unsigned long long)p.nG)) prim = 0u;
         const float4 oo = q.org[owner];
         const float2 dd = q.dir[owner];
         const f3 o = mk(oo.x, oo.y, oo.z), d = mk(oo.w, dd.x, dd.y);
@@ -858,7 +872,11 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
         uint32_t kh = reinterpret_cast<const uint32_t *>(q.key)[2 * owner + 1];
         kh = kh < 0x7F800000u ? kh : 0x7F800000u;
         const float tmax = (__uint_as_float(kh) + 1e-3f) * 1.0011f;
-        const unsigned char *nd = w.nodes + index * (uint32_t)(W4_FLOATS * 4);
+        // (lanes whose entry is a leaf or that have none read node 0: a leaf's index is a PRIMITIVE index, and with the
+        // nodes in global memory -- GEOM_WALK4G -- reading "node" 5 999 of a 2 400-node hierarchy is a page fault: it
+        // was one, whenever the pages behind the node array happened to be unmapped)
+        const uint32_t nidx = (inner && dbgInRange(p, 20, index, (unsigned long long)p.nnodes4)) ? index : 0u;
+        const unsigned char *nd = w.nodes + nidx * (uint32_t)(W4_FLOATS * 4);
         const uint32_t sg = __float_as_uint(B.z);
         const uint32_t sx = sg & 0xFFu, sy = (sg >> 8) & 0xFFu, sz = sg >> 16;
         const float4 nx = *reinterpret_cast<const float4 *>(nd + sx), fx = *reinterpret_cast<const float4 *>(nd + (sx ^ 16u));
@@ -1170,6 +1188,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                 }
             }
         } else {
+            if (valid && !dbgInRange(p, 1, i, (unsigned long long)p.segcap * (unsigned long long)p.nshard)) valid = false;
             if (valid) {
                 const float2 c = in.c[i];
                 pix = __float_as_uint(c.y);
@@ -1412,6 +1431,8 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                 dst = off + rank;
             }
             dst += out_base;
+            if (alive && !dbgInRange(p, 4, dst, (unsigned long long)p.segcap * (unsigned long long)p.nshard)) alive = false;
+            if (alive && !dbgInRange(p, 5, dst - out_base, p.segcap)) alive = false;
             if (alive) {
                 out.a[dst] = make_float4(o.x, o.y, o.z, d.x);
                 out.b[dst] = make_float4(d.y, d.z, T.x, T.y);

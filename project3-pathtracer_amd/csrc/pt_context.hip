@@ -1374,6 +1374,8 @@ int pt_get_stats(pt_ctx *c, pt_stats *out)
         fprintf(stderr, "[ptamd] shader clocks per chunk (wave latency): bounce 0: load/gen %.0f, nearest hit %.0f, shade+write %.0f; later: %.0f, %.0f, %.0f\n",
                 (double)h.dbg[0] / h.dbg[3], (double)h.dbg[1] / h.dbg[3], (double)h.dbg[2] / h.dbg[3],
                 (double)h.dbg[4] / h.dbg[7], (double)h.dbg[5] / h.dbg[7], (double)h.dbg[6] / h.dbg[7]);
+    if (getenv("PT_DEBUG_BOUNDS") && h.dbg[0])
+        fprintf(stderr, "[ptamd] BOUNDS violation: code %llu value %llu limit %llu block %llu thread %llu\n", h.dbg[0], h.dbg[1], h.dbg[2], h.dbg[4], h.dbg[5]);
     if (getenv("PT_DEBUG_PHASE2") && h.dbg[7])
         fprintf(stderr, "[ptamd] later bounces, shader clocks per chunk: load %.0f | nearest hit %.0f (pre-test + full batches %.0f, last batches %.0f, "
                         "result %.0f) | shade + radiance write %.0f | compaction + pool write %.0f\n",

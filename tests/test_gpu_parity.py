@@ -622,10 +622,12 @@ def test_multi_device_handle_with_strips(pkg, ndev, strip):
         L.pt_multi_destroy(m)
 
 
-@pytest.mark.parametrize("n_prims,paths", [(1500, (0, 4)), (6000, (0,))])
+@pytest.mark.parametrize("n_prims,paths", [(1500, (0, 4, 8)), (6000, (0, 8))])
 def test_very_large_primitive_lists(pkg, n_prims, paths):
-    """1 500 primitives: the hierarchy needs more than 64 KiB of LDS per workgroup (asked for explicitly); 6 000: it no
-    longer fits the CU at all and the library falls back to the scalar loop with the per-wave cull.  Same bits."""
+    """1 500 primitives: the binary hierarchy needs more than 64 KiB of LDS per workgroup (asked for explicitly) and the
+    4-wide one no longer fits beside the per-wave queues: the library reads its nodes through L1/L2 (geom_path 8); 6 000
+    likewise.  Same bits.  (Round 2 found a real bug here: lanes holding a leaf entry read "node" <primitive index> --
+    harmless garbage from LDS, a page fault from global memory whenever the pages behind the node array were unmapped.)"""
     geoms, mats, eye, view, up, fovy = _random_scene(4242, n_prims)
     W, H, depth = 48, 32, 3
     ga = (O.StaticGeom * len(geoms))(*geoms)
