@@ -1218,6 +1218,8 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
         float ldist = 0.0f;
         if (valid) {
             if (h.any) {
+                dbgInRange(p, 8, h.prim, (unsigned long long)p.nG);
+                dbgInRange(p, 9, h.material, (unsigned long long)p.nM);
                 const uint32_t m = h.material;
                 const float emit = s_mats[M_EMIT * p.nM + m];
                 if (emit > 0.0f) {
@@ -1378,6 +1380,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
             if (valid) {
                 // the plane entry accumulates along the path: set at bounce 0, added to afterwards (exclusive owner)
                 float *lp = p.lbuf + 3u * ((size_t)((pix >> SLOT_SHIFT) & (uint32_t)(MAXSLOT - 1)) * npix + (size_t)(pix & PIX_MASK));
+                if (!dbgInRange(p, 6, (unsigned long long)((pix >> SLOT_SHIFT) & (uint32_t)(MAXSLOT - 1)) * npix + (pix & PIX_MASK), (unsigned long long)npix * st->nslot)) lp = p.lbuf;
                 if (FIRST) {
                     lp[0] = L.x;
                     lp[1] = L.y;
@@ -1392,6 +1395,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
             // the path ends here: its radiance sample goes to this iteration slot's plane; k_accumulate folds
             // the planes into the running mean in iteration order once the launch sequence is done
             float *lp = p.lbuf + 3u * ((size_t)(pix >> SLOT_SHIFT) * npix + (size_t)(pix & PIX_MASK));
+            if (!dbgInRange(p, 7, (unsigned long long)(pix >> SLOT_SHIFT) * npix + (pix & PIX_MASK), (unsigned long long)npix * st->nslot)) lp = p.lbuf;
             lp[0] = L.x;
             lp[1] = L.y;
             lp[2] = L.z;
