@@ -194,6 +194,35 @@ __global__ __launch_bounds__(256) void k_accumulate(float *image, const float *l
     }
 }
 
+// The same on four consecutive floats per thread: the update does not care which channel a float is, so the image and
+// every radiance plane are flat arrays of 3*npix floats read as float4 (one 16-byte load per plane, all of a thread's
+// loads in flight before the dependent chain of divisions starts).  n4 = 3*npix/4 (the host checks divisibility and the
+// 16-byte alignment of both buffers, else the scalar kernel above runs).
+__global__ __launch_bounds__(256) void k_accumulate4(float4 *image, const float4 *lbuf, const IterState *st, int n4)
+{
+    const uint32_t iter0 = st->iter;
+    const int nslot = (int)st->nslot;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+        float4 a = image[i];
+        float4 L[PT_MAX_BATCH];
+#pragma unroll
+        for (int k = 0; k < PT_MAX_BATCH; ++k)
+            if (k < nslot) L[k] = lbuf[(size_t)k * (size_t)n4 + (size_t)i];
+#pragma unroll
+        for (int k = 0; k < PT_MAX_BATCH; ++k) {
+            if (k < nslot) {
+                const uint32_t it = iter0 + (uint32_t)k;
+                const float fi = (float)it, fim1 = (float)(it - 1u);
+                a.x = (it == 1u) ? L[k].x : (a.x * fim1 + L[k].x) / fi;
+                a.y = (it == 1u) ? L[k].y : (a.y * fim1 + L[k].y) / fi;
+                a.z = (it == 1u) ? L[k].z : (a.z * fim1 + L[k].z) / fi;
+                a.w = (it == 1u) ? L[k].w : (a.w * fim1 + L[k].w) / fi;
+            }
+        }
+        image[i] = a;
+    }
+}
+
 __global__ void k_iter_fold(IterState *st, int depth)
 {
     const int b = threadIdx.x;
@@ -311,10 +340,16 @@ hipError_t launch_iter_begin(hipStream_t s, IterState *st, int npix, int depth, 
 
 hipError_t launch_accumulate(hipStream_t s, float *image, const float *lbuf, const IterState *st, int npix)
 {
-    int grid = (npix + 255) / 256;
+    const bool vec = (3ll * npix) % 4 == 0 && ((uintptr_t)image | (uintptr_t)lbuf) % 16 == 0;
+    const int n = vec ? (int)(3ll * npix / 4) : npix;
+    int grid = (n + 255) / 256;
     if (grid > 8192) grid = 8192;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(256), 0, s, image, lbuf, st, npix);
+    if (vec)
+        hipLaunchKernelGGL(k_accumulate4, dim3(grid), dim3(256), 0, s, reinterpret_cast<float4 *>(image),
+                           reinterpret_cast<const float4 *>(lbuf), st, n);
+    else
+        hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(256), 0, s, image, lbuf, st, npix);
     return hipGetLastError();
 }
 
