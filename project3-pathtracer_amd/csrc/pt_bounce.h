@@ -428,6 +428,8 @@ struct PairQueue {
     float4 *best;                 // [64] per owner lane: (hit point xyz, meta) of the current minimum
     float4 *org;                  // [64] per owner lane: the ray, (origin.xyz, direction.x) ...
     float2 *dir;                  // [64] ... (direction.y, direction.z)
+    f3 po, pd;                    // org == nullptr (batched walk): the calling lane's OWN ray; a pair's lane fetches its owner's
+                                  // through ds_bpermute instead of from an LDS copy (1.5 KB per wave less)
     unsigned long long *dbg;
 };
 static constexpr uint32_t PAIR_QUEUE_BYTES = 2 * QCAP * 4 + 64 * 8 + 2 * 64 * 16 + 64 * 8;
@@ -443,18 +445,30 @@ __device__ __forceinline__ void pairBatch(const KParams &p, const PR *s_prims, c
     unsigned long long mykey = KEY_NONE;
     uint32_t owner = 0u;
     float4 mine = make_float4(0, 0, 0, 0);
-    if (lane < nb + nb2) {
-        // TYPE 3: a batch of (ray, triangle) pairs from the triangle queue
+    const bool busy = lane < nb + nb2;
+    // TYPE 3: a batch of (ray, triangle) pairs from the triangle queue
+    const uint32_t e = !busy ? 0u
+                       : (TYPE == 3u) ? q.tq[(head + lane) & (QCAP - 1u)]
+                       : ((TYPE == 2u && lane >= nb) ? q.q[1][(head2 + lane - nb) & (QCAP - 1u)]
+                                                     : q.q[(TYPE == 2u || TYPE == 3u) ? 0u : TYPE][(head + lane) & (QCAP - 1u)]);
+    owner = e & 63u;
+    f3 o = mk(0, 0, 0), d = mk(0, 0, 0);
+    if (q.org == nullptr) {                                  // (known at compile time; every lane of the wave is here)
+        const int oaddr = (int)(owner << 2);
+        auto fetch = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(v))); };
+        o = mk(fetch(q.po.x), fetch(q.po.y), fetch(q.po.z));
+        d = mk(fetch(q.pd.x), fetch(q.pd.y), fetch(q.pd.z));
+    }
+    if (busy) {
         const uint32_t type = (TYPE == 2u) ? (lane < nb ? 0u : 1u) : TYPE;
-        const uint32_t e = (TYPE == 3u) ? q.tq[(head + lane) & (QCAP - 1u)]
-                           : ((TYPE == 2u && lane >= nb) ? q.q[1][(head2 + lane - nb) & (QCAP - 1u)]
-                                                         : q.q[(TYPE == 2u || TYPE == 3u) ? 0u : TYPE][(head + lane) & (QCAP - 1u)]);
-        owner = e & 63u;
         uint32_t prim = e >> 8;
         if (!dbgInRange(p, 10 + (int)TYPE, prim, (unsigned long long)p.nG)) prim = 0u;
-        const float4 oo = q.org[owner];
-        const float2 dd = q.dir[owner];
-        const f3 o = mk(oo.x, oo.y, oo.z), d = mk(oo.w, dd.x, dd.y);
+        if (q.org != nullptr) {
+            const float4 oo = q.org[owner];
+            const float2 dd = q.dir[owner];
+            o = mk(oo.x, oo.y, oo.z);
+            d = mk(oo.w, dd.x, dd.y);
+        }
         const float4 *iv = reinterpret_cast<const float4 *>(s_prims[prim].inv);
         const float4 i0 = iv[0], i1 = iv[1], i2 = iv[2];
         const float inv[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
@@ -766,12 +780,15 @@ __device__ __forceinline__ Hit nearestHitWalkPairs(const KParams &p, const Prim 
 // GEOM_WALK4
 // ---------------------------------------------------------------------------------------------------------------
 static constexpr uint32_t W4_STACK = 384;                              // traversal entries per wave
-// per wave: the pair queue, then ray reciprocals, the entry ring and -- only when the scene has triangles -- their queue
-__host__ __device__ constexpr uint32_t walk4_wave_bytes(int ntri) { return PAIR_QUEUE_BYTES + 64 * 32 + W4_STACK * 4 + (ntri > 0 ? QCAP * 4 : 0); }
+// per wave: the two pair queues, keys and best hits (2.5 KB), the entry ring and -- only when the scene has triangles --
+// their queue: 4 KB.  The rays and their reciprocals stay in their owners' registers and reach the lane that tests an
+// entry or a pair through ds_bpermute, which costs no LDS storage (it was 7.5 KB with LDS copies of both, and 9 VGPRs
+// more for their address arithmetic): three 512-thread workgroups per CU beside a 13 KB node copy instead of two.
+static constexpr uint32_t W4_PAIR_BYTES = 2 * QCAP * 4 + 64 * 8 + 64 * 16;
+__host__ __device__ constexpr uint32_t walk4_wave_bytes(int ntri) { return W4_PAIR_BYTES + W4_STACK * 4 + (ntri > 0 ? QCAP * 4 : 0); }
 struct Walk4 {
     const unsigned char *nodes;   // LDS copy of the 4-wide hierarchy (ptd::W4_FLOATS floats per node)
-    float4 *inv;                  // [64][2] per owner lane: (1/d.xyz, -o.x/d.x) (-o.y/d.y, -o.z/d.z, near-plane byte offsets, 0)
-    uint32_t *stack;              // [W4_STACK] owner lane | child word (bit 31 leaf, bit 30 cube, bit 29 triangle, bits 6..28 index)
+    uint32_t *stack;              // [W4_STACK] owner lane | direction signs << 6 | child word (bit 31 leaf, bit 30 cube, bit 29 triangle, bits 9..28 index)
 };
 
 // append the lanes' (ray, triangle) pairs and run a batch when one is full; every lane of the wave must make the call
@@ -792,20 +809,15 @@ template <bool FIRST>
 __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *prims, const Walk4 w, const PairQueue q,
                                                f3 o, f3 d, bool valid, uint32_t lane)
 {
-    q.key[lane] = KEY_NONE;
-    q.org[lane] = make_float4(o.x, o.y, o.z, d.x);
-    q.dir[lane] = make_float2(d.y, d.z);
+    q.key[lane] = KEY_NONE;                                  // (q.po / q.pd: the ray stays in this lane's registers)
     uint32_t head[2] = {0u, 0u}, tail[2] = {0u, 0u};        // wave-uniform
     uint32_t thead = 0u, ttail = 0u;                         // the triangle queue
     const f3 dinv = approxInverse(d);
     const f3 oinv = mk(-(o.x * dinv.x), -(o.y * dinv.y), -(o.z * dinv.z));
-    {
-        // byte offset of the near planes inside an axis' 32 bytes: the hi planes (16) when the ray runs towards -axis
-        const uint32_t sx = (__float_as_uint(dinv.x) >> 31) << 4, sy = (__float_as_uint(dinv.y) >> 31) << 4,
-                       sz = (__float_as_uint(dinv.z) >> 31) << 4;
-        w.inv[2 * lane] = make_float4(dinv.x, dinv.y, dinv.z, oinv.x);
-        w.inv[2 * lane + 1] = make_float4(oinv.y, oinv.z, __uint_as_float(sx | (sy << 8) | (sz << 16)), 0.0f);
-    }
+    // the ray's three direction signs travel IN its entries (bits 6..8), so a popped entry addresses its node's near and
+    // far planes by itself and the node reads go out together with the reads of the owner's ray (one LDS round trip
+    // less per step than with the signs parked beside the reciprocals)
+    const uint32_t mysigns = ((__float_as_uint(dinv.x) >> 31) << 6) | ((__float_as_uint(dinv.y) >> 31) << 7) | ((__float_as_uint(dinv.z) >> 31) << 8);
     // 1. the scene-spanning primitives (walls, big lights), wave-uniformly: box pre-test, pairs
     for (int k = 0; k < p.nbig; ++k) {
         const int g = p.big[k];
@@ -830,7 +842,7 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
     if (p.nnodes4 > 0) {
         const uint64_t vm = __ballot(valid);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
-        if (valid) w.stack[rank] = lane;                      // owner | node 0
+        if (valid) w.stack[rank] = lane | mysigns;            // owner | signs | node 0
         top = (uint32_t)__popcll(vm);
     }
     // The entries live in a ring (a deque): pushes go to its tail; a step pops its nb oldest entries from the HEAD while
@@ -857,7 +869,7 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
         top -= nb;
         if (DEBUG_BVH) { dbg_steps++; dbg_entries += nb; }
         const bool leaf = act && (e >> 31) != 0u;
-        const uint32_t owner = e & 63u, index = (e >> 6) & 0x7FFFFFu;
+        const uint32_t owner = e & 63u, index = (e >> 9) & 0xFFFFFu;
         if (__ballot(leaf) != 0ull) {
             const bool cube = (e & 0x40000000u) != 0u, tri = (e & 0x20000000u) != 0u;
             pushPairs<FIRST>(p, prims, q, head, tail, leaf && !cube && !tri, leaf && cube, index, lane, owner);
@@ -866,7 +878,11 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
         const bool inner = act && (e >> 31) == 0u;
         const uint64_t im = __ballot(inner);
         if (im == 0ull) continue;
-        const float4 A = w.inv[2 * owner], B = w.inv[2 * owner + 1];
+        // the owner's (1/d, -o/d) out of ITS registers (every lane of the wave is here: uniform control flow)
+        const int oaddr = (int)(owner << 2);
+        auto fetch = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(oaddr, __float_as_int(v))); };
+        const float4 A = make_float4(fetch(dinv.x), fetch(dinv.y), fetch(dinv.z), fetch(oinv.x));
+        const float2 B = make_float2(fetch(oinv.y), fetch(oinv.z));
         // the owner's best hit so far bounds the boxes worth entering (reported distances fall short of the true ones by
         // getPointOnRay's epsilon and |d| is 1 +- 1e-6: the slack covers both); no hit yet: all-ones key -> +inf
         uint32_t kh = reinterpret_cast<const uint32_t *>(q.key)[2 * owner + 1];
@@ -877,8 +893,8 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
         // was one, whenever the pages behind the node array happened to be unmapped)
         const uint32_t nidx = (inner && dbgInRange(p, 20, index, (unsigned long long)p.nnodes4)) ? index : 0u;
         const unsigned char *nd = w.nodes + nidx * (uint32_t)(W4_FLOATS * 4);
-        const uint32_t sg = __float_as_uint(B.z);
-        const uint32_t sx = sg & 0xFFu, sy = (sg >> 8) & 0xFFu, sz = sg >> 16;
+        // byte offset of the near planes inside an axis' 32 bytes: the hi planes (16) when the ray runs towards -axis
+        const uint32_t sx = (e >> 2) & 16u, sy = (e >> 3) & 16u, sz = (e >> 4) & 16u;
         const float4 nx = *reinterpret_cast<const float4 *>(nd + sx), fx = *reinterpret_cast<const float4 *>(nd + (sx ^ 16u));
         const float4 ny = *reinterpret_cast<const float4 *>(nd + 32 + sy), fy = *reinterpret_cast<const float4 *>(nd + 32 + (sy ^ 16u));
         const float4 nz = *reinterpret_cast<const float4 *>(nd + 64 + sz), fz = *reinterpret_cast<const float4 *>(nd + 64 + (sz ^ 16u));
@@ -897,7 +913,7 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
             if (mask == 0ull) continue;
             const bool pass = __builtin_amdgcn_inverse_ballot_w64(mask);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            if (pass) w.stack[wrap(wrap(qh + top) + rank)] = owner | cha[c];
+            if (pass) w.stack[wrap(wrap(qh + top) + rank)] = (e & 0x1FFu) | cha[c];
             top += (uint32_t)__popcll(mask);
         }
     }
@@ -962,9 +978,12 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const PrimPad *s_pri
         if (GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) {
             Walk4 w4;
             w4.nodes = (GEOM == GEOM_WALK4G) ? reinterpret_cast<const unsigned char *>(p.bvh4) : reinterpret_cast<const unsigned char *>(s_nodes);
-            w4.inv = reinterpret_cast<float4 *>(b + PAIR_QUEUE_BYTES);
-            w4.stack = reinterpret_cast<uint32_t *>(b + PAIR_QUEUE_BYTES + 64 * 32);
-            pq.tq = reinterpret_cast<uint32_t *>(b + PAIR_QUEUE_BYTES + 64 * 32 + W4_STACK * 4);
+            w4.stack = reinterpret_cast<uint32_t *>(b + W4_PAIR_BYTES);
+            pq.tq = reinterpret_cast<uint32_t *>(b + W4_PAIR_BYTES + W4_STACK * 4);
+            pq.org = nullptr;                                    // rays by ds_bpermute from their owners' registers
+            pq.dir = nullptr;
+            pq.po = o;
+            pq.pd = d;
             return nearestHitWalk4<FIRST>(p, p.prims, w4, pq, o, d, want, lane);
         }
         if (GEOM == GEOM_WALK_PAIR) return nearestHitWalkPairs<FIRST>(p, p.prims, s_nodes, pq, o, d, want, lane);

@@ -225,8 +225,8 @@ void build_bvh(const std::vector<Aabb> &boxes, std::vector<int> &idx, size_t lo,
 // node i is i + 1, the right child is nodes[i + 1].skip): a wide node takes the two children of a binary node and keeps
 // replacing the child with the largest box by that child's own two children until it has four (or only leaves are left).
 // Record = ptd::W4_FLOATS floats: per axis the four children's lo planes then their hi planes (x: [0..8), y: [8..16),
-// z: [16..24)), then four child words (bit 31 leaf, bit 30 cube, bit 29 triangle, bits 6..28 node / primitive index; the low
-// six bits stay free for the owner lane of a traversal entry).  An empty child has lo = +3e38, hi = -3e38: no ray passes.
+// z: [16..24)), then four child words (bit 31 leaf, bit 30 cube, bit 29 triangle, bits 9..28 node / primitive index; the low
+// nine bits stay free for the owner lane and the three direction signs of a traversal entry).  An empty child has lo = +3e38, hi = -3e38: no ray passes.
 int build_wide4(const std::vector<ptd::BvhNode> &bin, const std::vector<int> &ptype, int b, int depth,
                 std::vector<float> &out, int &maxdepth)
 {
@@ -259,9 +259,9 @@ int build_wide4(const std::vector<ptd::BvhNode> &bin, const std::vector<int> &pt
             for (int a = 0; a < 3; ++a) { lo[a] = n.lo[a]; hi[a] = n.hi[a]; }
             if (n.prim >= 0) {
                 const uint32_t prim = (uint32_t)n.prim & 0x3FFFFFFFu;
-                word = 0x80000000u | (ptype[prim] == PT_CUBE ? 0x40000000u : 0u) | (ptype[prim] == 3 ? 0x20000000u : 0u) | (prim << 6);
+                word = 0x80000000u | (ptype[prim] == PT_CUBE ? 0x40000000u : 0u) | (ptype[prim] == 3 ? 0x20000000u : 0u) | (prim << 9);
             } else {
-                word = (uint32_t)build_wide4(bin, ptype, kids[(size_t)c], depth + 1, out, maxdepth) << 6;
+                word = (uint32_t)build_wide4(bin, ptype, kids[(size_t)c], depth + 1, out, maxdepth) << 9;
             }
         }
         float *rec = out.data() + (size_t)me * ptd::W4_FLOATS;       // (re-fetched: the recursion grows the vector)
@@ -691,7 +691,7 @@ int configure(pt_ctx *c)
     k.nshard = (cfg.compact == 1) ? pt::NSHARD : 1;
     size_t lds = pt::bounce_lds_bytes(k, cfg);
     if ((cfg.geom == 6 || cfg.geom == 7) && o.workgroup == 0) {
-        // the batched walk keeps 7.5 KiB of LDS per wave beside the node copy: take the workgroup size that puts most
+        // the batched walk keeps 5.5 KiB of LDS per wave beside the node copy: take the workgroup size that puts most
         // waves on a CU (a larger workgroup shares one node copy among more waves)
         int best_wg = cfg.workgroup;
         long long best_waves = 0;
