@@ -779,7 +779,7 @@ __device__ __forceinline__ Hit nearestHitWalkPairs(const KParams &p, const Prim 
 // ---------------------------------------------------------------------------------------------------------------
 // GEOM_WALK4
 // ---------------------------------------------------------------------------------------------------------------
-static constexpr uint32_t W4_STACK = 384;                              // traversal entries per wave
+static constexpr uint32_t W4_STACK = 512;                              // traversal entries per wave (a power of two: the ring wraps with an AND)
 // per wave: the two pair queues, keys and best hits (2.5 KB), the entry ring and -- only when the scene has triangles --
 // their queue: 4 KB.  The rays and their reciprocals stay in their owners' registers and reach the lane that tests an
 // entry or a pair through ds_bpermute, which costs no LDS storage (it was 7.5 KB with LDS copies of both, and 9 VGPRs
@@ -854,7 +854,7 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
     const int reserve = 3 * p.wdepth + 4;
     uint32_t qh = 0u;                                         // ring index of the oldest entry (wave-uniform)
     uint32_t dbg_steps = 0, dbg_entries = 0;
-    auto wrap = [](uint32_t x) -> uint32_t { const uint32_t y = x - W4_STACK; return y < x ? y : x; };   // x < 2 * W4_STACK
+    auto wrap = [](uint32_t x) -> uint32_t { return x & (W4_STACK - 1u); };
     while (top != 0u) {                                       // top = entries in the ring
         const bool fifo = (int)top + 3 * 64 <= (int)W4_STACK - reserve;
         uint32_t nb = top < 64u ? top : 64u;
