@@ -21,6 +21,10 @@ static constexpr uint32_t DEAD = 0xFFFFFFFFu;
 #ifndef PT_DEBUG_BVH
 #define PT_DEBUG_BVH 0
 #endif
+#ifndef PT_DEBUG_SPAN
+#define PT_DEBUG_SPAN 0
+#endif
+static constexpr bool DEBUG_SPAN = PT_DEBUG_SPAN != 0;       // workgroup lifetimes of the bounce-1 launches into IterState::dbg
 #ifndef PT_DEBUG_BOUNDS
 #define PT_DEBUG_BOUNDS 0
 #endif
@@ -1094,6 +1098,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
     const uint32_t iter = st->iter;
     unsigned long long clk0 = 0, rt0 = 0;
     if (bounce == 1 && blockIdx.x == 0 && tid == 0) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+    const unsigned long long span0 = (DEBUG_SPAN && bounce == 1 && tid == 0) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const RayPool in = p.pool[bounce & 1];
     const RayPool out = p.pool[(bounce + 1) & 1];
     const bool last = (bounce == p.depth - 1);
@@ -1496,6 +1501,20 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
         atomicAdd(&st->dbg[base + 1], ph[1]);
         atomicAdd(&st->dbg[base + 2], ph[2]);
         atomicAdd(&st->dbg[base + 3], ph[4]);
+    }
+    if (DEBUG_SPAN && bounce == 1 && tid == 0) {
+        // lifetime of this workgroup in the bounce-1 launch (10 ns ticks)
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(), life = t1 - span0;
+#if PT_DEBUG_SPAN == 2
+        atomicAdd(&st->dbg[blockIdx.x & 7], life);          // per XCD (workgroups go round the 8 XCDs in dispatch order)
+#else
+        atomicAdd(&st->dbg[0], life);                       // sum, count, longest, shortest (as max of the complement)
+        atomicAdd(&st->dbg[1], 1ull);
+        atomicMax(&st->dbg[2], life);
+        atomicMax(&st->dbg[3], ~life);
+        atomicMax(&st->dbg[4], ~span0);                     // earliest start / latest end over all launches so far
+        atomicMax(&st->dbg[5], t1);
+#endif
     }
     if (bounce == 1 && blockIdx.x == 0 && tid == 0) {      // clock diagnostics (one thread per launch)
         st->clk[0] = __builtin_amdgcn_s_memtime() - clk0;

@@ -1357,6 +1357,14 @@ int pt_get_stats(pt_ctx *c, pt_stats *out)
     if (getenv("PT_DEBUG_CLOCK") && h.clk[1])
         fprintf(stderr, "[ptamd] bounce-1 workgroup 0: %llu shader clocks in %llu x 10 ns -> %.0f MHz\n", h.clk[0], h.clk[1],
                 (double)h.clk[0] / (double)h.clk[1] * 100.0);
+    if (getenv("PT_DEBUG_SPAN") && atoi(getenv("PT_DEBUG_SPAN")) == 2) {     // -DPT_DEBUG_SPAN=2 builds
+        fprintf(stderr, "[ptamd] bounce-1 workgroup lifetime sums by blockIdx %% 8 (10 ns ticks):");
+        for (int x = 0; x < 8; ++x) fprintf(stderr, " %llu", h.dbg[x]);
+        fprintf(stderr, "\n");
+    } else if (getenv("PT_DEBUG_SPAN") && h.dbg[1])                          // -DPT_DEBUG_SPAN=1 builds
+        fprintf(stderr, "[ptamd] bounce-1 workgroups: %llu lifetimes, mean %.1f us, shortest %.1f us, longest %.1f us; first start to last end over all launches %.1f us\n",
+                h.dbg[1], (double)h.dbg[0] / (double)h.dbg[1] * 0.01, (double)(~h.dbg[3]) * 0.01, (double)h.dbg[2] * 0.01,
+                (double)(h.dbg[5] - ~h.dbg[4]) * 0.01);
     out->bounce_launches = c->bounce_launches;
     out->shadow_rays = h.shadow_rays;
     for (pt_ctx *ch : c->slice_ctx) {                    // motion blur: the slices did the work
