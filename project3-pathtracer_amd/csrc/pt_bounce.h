@@ -785,7 +785,7 @@ __device__ __forceinline__ Hit nearestHitWalkPairs(const KParams &p, const Prim 
 // ---------------------------------------------------------------------------------------------------------------
 static constexpr uint32_t W4_STACK = 512;                              // traversal entries per wave (a power of two: the ring wraps with an AND)
 // per wave: the two pair queues, keys and best hits (2.5 KB), the entry ring and -- only when the scene has triangles --
-// their queue: 4 KB.  The rays and their reciprocals stay in their owners' registers and reach the lane that tests an
+// their queue: 4.5 KB.  The rays and their reciprocals stay in their owners' registers and reach the lane that tests an
 // entry or a pair through ds_bpermute, which costs no LDS storage (it was 7.5 KB with LDS copies of both, and 9 VGPRs
 // more for their address arithmetic): three 512-thread workgroups per CU beside a 13 KB node copy instead of two.
 static constexpr uint32_t W4_PAIR_BYTES = 2 * QCAP * 4 + 64 * 8 + 64 * 16;

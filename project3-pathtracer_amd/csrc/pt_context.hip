@@ -691,7 +691,7 @@ int configure(pt_ctx *c)
     k.nshard = (cfg.compact == 1) ? pt::NSHARD : 1;
     size_t lds = pt::bounce_lds_bytes(k, cfg);
     if ((cfg.geom == 6 || cfg.geom == 7) && o.workgroup == 0) {
-        // the batched walk keeps 5.5 KiB of LDS per wave beside the node copy: take the workgroup size that puts most
+        // the batched walk keeps 4.5 KiB of LDS per wave beside the node copy: take the workgroup size that puts most
         // waves on a CU (a larger workgroup shares one node copy among more waves)
         int best_wg = cfg.workgroup;
         long long best_waves = 0;
