@@ -509,7 +509,7 @@ __device__ __forceinline__ void pairBatch(const KParams &p, const PR *s_prims, c
 // Must be entered by all 64 lanes of the wave (lanes without a ray pass valid = false).
 template <bool FIRST, class PR>
 __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_prims, const float4 *s_boxes, const PairQueue q,
-                                               f3 o, f3 d, bool valid, uint32_t lane)
+                                               f3 o, f3 d, bool valid, uint32_t lane, uint32_t primmask)
 {
     const unsigned long long ph_in = (DEBUG_PHASE2 && !FIRST) ? __builtin_amdgcn_s_memtime() : 0ull;
     q.key[lane] = KEY_NONE;
@@ -525,6 +525,10 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
         const_u32_ptr hp = (const_u32_ptr)(uintptr_t)(p.prims + g);
         const uint32_t type = hp[0];
         if (type > 1u) continue;                             // MESH: never has geometry
+        // camera rays: the host's table says which primitives the 64 pixels of this chunk can see at all (primmask, bit g;
+        // all ones without a table).  The bounds-checking build runs the test anyway and reports a pair that passes.
+        const bool culled = FIRST && ((primmask >> ((uint32_t)g & 31u)) & 1u) == 0u;
+        if (culled && !DEBUG_BOUNDS) continue;
         // padded world box of the primitive against this lane's ray (camera rays: box relative to the shared eye), through
         // an LDS broadcast read: VGPR operands keep the six fma at the full VALU rate (SGPR operands halve it)
         const float4 lo4 = s_boxes[2 * g], hi4 = s_boxes[2 * g + 1];
@@ -537,6 +541,7 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
         // the compare's lane mask straight from v_cmp, and back into a predicate without VALU work
         const uint64_t mask = __builtin_amdgcn_fcmpf(tn, tf, FCMP_OLE) & vmask;
         if (mask == 0ull) continue;
+        if (DEBUG_BOUNDS && culled) { dbgInRange(p, 30, (unsigned long long)g + 1000ull, 0ull); continue; }
         const bool pass = __builtin_amdgcn_inverse_ballot_w64(mask);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         if (type == 0u) {                                    // wave-uniform
@@ -965,7 +970,7 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
 // (the hit queue uses all 64 lanes as workers whatever their own ray).
 template <int GEOM, bool FIRST>
 __device__ __forceinline__ Hit nearestHit(const KParams &p, const PrimPad *s_prims, const float4 *s_nodes, const WaveQueue &wq,
-                                          f3 o, f3 d, bool want, uint32_t lane)
+                                          f3 o, f3 d, bool want, uint32_t lane, uint32_t primmask = 0xFFFFFFFFu)
 {
     if (GEOM == GEOM_QUEUE) return nearestHitQueued<FIRST>(p, s_prims, wq, o, d, want, lane);
     if (GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR || GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) {
@@ -991,7 +996,7 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const PrimPad *s_pri
             return nearestHitWalk4<FIRST>(p, p.prims, w4, pq, o, d, want, lane);
         }
         if (GEOM == GEOM_WALK_PAIR) return nearestHitWalkPairs<FIRST>(p, p.prims, s_nodes, pq, o, d, want, lane);
-        return nearestHitPairs<FIRST>(p, s_prims, s_nodes, pq, o, d, want, lane);
+        return nearestHitPairs<FIRST>(p, s_prims, s_nodes, pq, o, d, want, lane, primmask);
     }
     Hit h;
     h.any = false;
@@ -1158,6 +1163,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
         uint32_t i;
         bool valid = locate(cur, R, i);
         const bool in_pool = valid;                               // the slot exists (COMPACT 0: it may hold a dead ray)
+        const uint32_t chunk_first_ray = (R * NW + wave) * 64u;   // (bounce 0: rays are numbered slot by slot, pixel by pixel)
         f3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(1, 1, 1);
         uint32_t pix = 0;
         if (FIRST) {
@@ -1231,8 +1237,17 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
         bool alive = false;
         const unsigned long long c1 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
         // camera rays share the eye (host-side eye transforms and eye-relative boxes) unless a lens spreads their origins
+        // camera rays of the pair path: which primitives the chunk's 64 pixels can see (host-built table, one word per 64
+        // tile-local pixels; the host only supplies it when every chunk is such a span: npix % 64 == 0, no lens)
+        uint32_t primmask = 0xFFFFFFFFu;
+        if (FIRST && GEOM == GEOM_PAIR && p.span_mask != nullptr) {
+            uint32_t b0 = chunk_first_ray;                                // wave-uniform
+            while (b0 >= npix) b0 -= npix;                               // the ray's tile-local pixel (at most MAXSLOT - 1 trips)
+            const_u32_ptr sm = (const_u32_ptr)(uintptr_t)(p.span_mask + (b0 >> 6));
+            primmask = sm[0];
+        }
         const Hit h = (FIRST && p.lens_radius > 0.0f) ? nearestHit<GEOM, false>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane)
-                                                      : nearestHit<GEOM, FIRST>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane);
+                                                      : nearestHit<GEOM, FIRST>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane, primmask);
         const unsigned long long c2 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
         f3 L = mk(0, 0, 0);               // radiance this vertex adds to the path's sample
         // direct lighting: the shadow ray this lane wants traced and what it is worth if the light is visible

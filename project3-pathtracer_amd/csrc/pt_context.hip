@@ -86,6 +86,9 @@ struct pt_ctx {
     float *d_ro_eye = nullptr;
     float *d_face_n = nullptr;
     float *d_box_eye = nullptr;
+    std::vector<float> h_box_eye;          // host copy (the span table of the camera rays is built from it)
+    uint32_t *d_span_mask = nullptr;
+    size_t span_mask_cap = 0;
     float *d_box_world = nullptr;
     int *d_lights = nullptr;    // direct lighting: indices of the emissive primitives
     ptd::BvhNode *d_bvh = nullptr;
@@ -564,6 +567,7 @@ int configure(pt_ctx *c)
                 be[8 * i + 4 + (size_t)a] = (float)(hi + pad);
             }
         }
+        c->h_box_eye = be;
         if (c->d_box_eye) { (void)hipFree(c->d_box_eye); c->d_box_eye = nullptr; }
         HIP_TRY(hipMalloc((void **)&c->d_box_eye, be.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(c->d_box_eye, be.data(), be.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -759,6 +763,88 @@ int configure(pt_ctx *c)
         c->lbuf_cap = lbuf_bytes;
     }
     k.lbuf = c->d_lbuf;
+
+    // Camera rays of the pair path: which primitives can the 64 pixels of a chunk see at all?  One word per span of 64
+    // tile-local pixels, bit g set unless primitive g's padded box lies wholly outside one of the four side planes of the
+    // span's pixel frustum (grown by a pixel on every side; a span that runs over a row end takes the whole rows) or wholly
+    // behind the eye.  Conservative: a cleared bit only ever drops (ray, primitive) pairs whose box pre-test would fail
+    // in every lane -- the bounds-checking build runs those pre-tests anyway and reports any that passes.  Needs chunks that
+    // are spans (npix % 64 == 0) and rays that start at the eye (no lens).
+    k.span_mask = nullptr;
+    if (cfg.geom == 4 && k.nG <= 32 && k.ntri == 0 && k.eye_cull && !(k.lens_radius > 0.0f) && npix % 64 == 0 &&
+        c->h_box_eye.size() >= (size_t)k.nG * 8) {
+        const int nspan = npix / 64;
+        std::vector<uint32_t> tab((size_t)nspan, 0u);
+        const double ex = k.eye[0], ey = k.eye[1], ez = k.eye[2];
+        const double vw[3] = {(double)k.M[0] - ex, (double)k.M[1] - ey, (double)k.M[2] - ez};
+        auto gpix = [&](uint32_t pl) -> uint32_t {
+            if (k.strip_span == 0u) return pl + k.pix_offset;
+            const uint32_t j = pl / k.strip_span;
+            return pl + k.strip_span * (j * (k.strip_world - 1u) + k.strip_rank);
+        };
+        auto dirOf = [&](double sx, double sy, double *o3) {
+            for (int a = 0; a < 3; ++a) o3[a] = vw[a] + (1.0 - 2.0 * sx) * (double)k.H[a] + (1.0 - 2.0 * sy) * (double)k.V[a];
+        };
+        for (int sp = 0; sp < nspan; ++sp) {
+            const uint32_t g0 = gpix((uint32_t)sp * 64u), g1 = gpix((uint32_t)sp * 64u + 63u);
+            const int y0 = (int)(g0 / (uint32_t)W), y1 = (int)(g1 / (uint32_t)W);
+            int xa = (int)(g0 % (uint32_t)W), xb = (int)(g1 % (uint32_t)W);
+            if (y0 != y1) { xa = 0; xb = W - 1; }
+            const int ya = y0 < y1 ? y0 : y1, yb = y0 < y1 ? y1 : y0;
+            const double sx0 = ((double)xa - 1.0) / (double)k.resx, sx1 = ((double)xb + 2.0) / (double)k.resx;
+            const double sy0 = ((double)ya - 1.0) / (double)k.resy, sy1 = ((double)yb + 2.0) / (double)k.resy;
+            double cn[4][3], cc[3];
+            dirOf(sx0, sy0, cn[0]); dirOf(sx1, sy0, cn[1]); dirOf(sx1, sy1, cn[2]); dirOf(sx0, sy1, cn[3]);
+            dirOf(0.5 * (sx0 + sx1), 0.5 * (sy0 + sy1), cc);
+            double nrm[4][3];
+            bool planes_ok = true;
+            for (int e = 0; e < 4; ++e) {
+                const double *a3 = cn[e], *b3 = cn[(e + 1) & 3];
+                double n3[3] = {a3[1] * b3[2] - b3[1] * a3[2], a3[2] * b3[0] - b3[2] * a3[0], a3[0] * b3[1] - b3[0] * a3[1]};
+                const double len = sqrt(n3[0] * n3[0] + n3[1] * n3[1] + n3[2] * n3[2]);
+                if (!(len > 1e-12)) { planes_ok = false; break; }
+                const double s = (n3[0] * cc[0] + n3[1] * cc[1] + n3[2] * cc[2]) > 0.0 ? -1.0 / len : 1.0 / len;    // outward: the centre is inside
+                for (int a = 0; a < 3; ++a) nrm[e][a] = n3[a] * s;
+            }
+            // "behind the eye" only when every corner direction is within 60 degrees of the centre direction
+            const double lcc = sqrt(cc[0] * cc[0] + cc[1] * cc[1] + cc[2] * cc[2]);
+            bool narrow = planes_ok && lcc > 1e-12;
+            for (int e = 0; e < 4 && narrow; ++e) {
+                const double l = sqrt(cn[e][0] * cn[e][0] + cn[e][1] * cn[e][1] + cn[e][2] * cn[e][2]);
+                if (!((cn[e][0] * cc[0] + cn[e][1] * cc[1] + cn[e][2] * cc[2]) > 0.5 * l * lcc)) narrow = false;
+            }
+            uint32_t m = 0u;
+            for (int g = 0; g < k.nG; ++g) {
+                const float *bx = &c->h_box_eye[(size_t)g * 8];
+                bool out = false;
+                double scale = 1.0;
+                for (int a = 0; a < 3; ++a) scale += fabs((double)bx[a]) + fabs((double)bx[4 + a]);
+                if (planes_ok) {
+                    for (int e = 0; e < 4 && !out; ++e) {
+                        double vmin = 0.0;          // the box corner deepest inside this plane
+                        for (int a = 0; a < 3; ++a) { const double lo = nrm[e][a] * (double)bx[a], hi = nrm[e][a] * (double)bx[4 + a]; vmin += lo < hi ? lo : hi; }
+                        if (vmin > 1e-5 * scale) out = true;
+                    }
+                    if (!out && narrow) {
+                        double vmax = 0.0;
+                        for (int a = 0; a < 3; ++a) { const double lo = cc[a] * (double)bx[a], hi = cc[a] * (double)bx[4 + a]; vmax += lo > hi ? lo : hi; }
+                        if (vmax < -1e-5 * scale * lcc) out = true;
+                    }
+                }
+                if (!out) m |= 1u << g;
+            }
+            tab[(size_t)sp] = m;
+        }
+        if (c->span_mask_cap < tab.size()) {
+            if (c->d_span_mask) (void)hipFree(c->d_span_mask);
+            c->d_span_mask = nullptr; c->span_mask_cap = 0;
+            HIP_TRY(hipMalloc((void **)&c->d_span_mask, tab.size() * sizeof(uint32_t)));
+            c->span_mask_cap = tab.size();
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));          // (launches of the previous configuration may still read the table)
+        HIP_TRY(hipMemcpy(c->d_span_mask, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        k.span_mask = c->d_span_mask;
+    }
 
     // ray pools: 2 x nshard segments of `segcap` rays x 40 B, carved from one allocation.  A segment must hold
     // every survivor its writers can produce in one launch: each wave appends at most 64 rays per round and runs
@@ -970,6 +1056,7 @@ void pt_destroy(pt_ctx *c)
     if (c->d_ro_eye) (void)hipFree(c->d_ro_eye);
     if (c->d_face_n) (void)hipFree(c->d_face_n);
     if (c->d_box_eye) (void)hipFree(c->d_box_eye);
+    if (c->d_span_mask) (void)hipFree(c->d_span_mask);
     if (c->d_box_world) (void)hipFree(c->d_box_world);
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_bvh) (void)hipFree(c->d_bvh);

@@ -427,6 +427,46 @@ def test_random_scenes_bit_exact(pkg, seed):
         check(img, ref, [int(x) for x in st.live_in[:depth]], [int(x) for x in live], f"random scene {seed} geom_path={geom_path}")
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_camera_span_table_is_conservative(pkg, seed):
+    """Pair path, camera rays: the host's table of the primitives each 64-pixel span can see (built when a tile's pixel
+    count is a multiple of 64 and there is no lens) must only drop pairs that would miss -- random cameras (inside
+    objects, narrow and very wide fields of view, rolled), random TRS primitives, whole frames, bands and strip tiles."""
+    rng = np.random.default_rng(4200 + seed)
+    n_prims = [3, 9, 20, 32][seed % 4]
+    geoms, mats, eye, view, up, _ = _random_scene(7000 + seed, n_prims)
+    W, H = [(64, 48), (96, 64), (128, 40), (192, 8), (32, 30)][seed % 5]
+    if (W * H) % 64:
+        H = (H + 63) // 64 * 64
+    fovy = float([8.0, 25.0, 42.0, 60.0][seed % 4] * rng.uniform(0.8, 1.1))
+    depth, iters = 4, 2
+    ga = (O.StaticGeom * len(geoms))(*geoms)
+    ma = (O.Material * len(mats))(*mats)
+    cam = O.make_camera(W, H, eye * (3.0 if seed % 3 == 0 else 1.0), view, up, fovy)      # every third camera outside the cluster
+    ref, live = O.render(ga, len(geoms), ma, len(mats), cam, depth, iters=iters, seed=seed)
+    tiles = [dict(), dict(geom_path=5)]
+    if H % 16 == 0:
+        tiles.append(dict(geom_path=5, strip_rows=8, strip_world=2, strip_rank=seed % 2))
+        tiles.append(dict(geom_path=5, row_begin=H // 2, row_end=H))
+    for opts in tiles:
+        with pkg.Renderer(0) as r:
+            r.set_options(depth=depth, seed=seed, **opts)
+            r.set_scene(C.cast(ga, C.POINTER(pkg.StaticGeom)), len(geoms), C.cast(ma, C.POINTER(pkg.Material)), len(mats))
+            r.set_camera(pkg.CameraData.from_buffer_copy(cam))
+            r.clear_image()
+            r.render(1, iters)
+            img = r.download_image()
+            st = r.stats()
+        if "strip_rows" in opts:
+            from project3_pathtracer_amd import sharding
+            rows = sharding.strip_global_rows(H, 2, opts["strip_rank"], 8)
+            assert np.array_equal(img.view(np.uint32), ref[rows].view(np.uint32)), f"span table, strips, seed {seed}"
+        elif "row_begin" in opts:
+            assert np.array_equal(img.view(np.uint32), ref[H // 2:].view(np.uint32)), f"span table, band, seed {seed}"
+        else:
+            check(img, ref, [int(x) for x in st.live_in[:depth]], [int(x) for x in live], f"span table seed {seed} {opts}")
+
+
 # ---------------------------------------------------------------- several contexts behind one handle (pt_multi_*)
 @pytest.mark.parametrize("ndev", [1, 2, 3])
 def test_multi_device_handle_matches_single_context(pkg, ndev):
