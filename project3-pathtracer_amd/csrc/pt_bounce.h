@@ -816,7 +816,7 @@ __device__ __forceinline__ void pushTriangles(const KParams &p, const Prim *prim
 // Must be entered by all 64 lanes of the wave.  prims: global records (gathered per lane through L1/L2).
 template <bool FIRST>
 __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *prims, const Walk4 w, const PairQueue q,
-                                               f3 o, f3 d, bool valid, uint32_t lane)
+                                               f3 o, f3 d, bool valid, uint32_t lane, uint32_t span)
 {
     q.key[lane] = KEY_NONE;                                  // (q.po / q.pd: the ray stays in this lane's registers)
     uint32_t head[2] = {0u, 0u}, tail[2] = {0u, 0u};        // wave-uniform
@@ -827,12 +827,25 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
     // far planes by itself and the node reads go out together with the reads of the owner's ray (one LDS round trip
     // less per step than with the signs parked beside the reciprocals)
     const uint32_t mysigns = ((__float_as_uint(dinv.x) >> 31) << 6) | ((__float_as_uint(dinv.y) >> 31) << 7) | ((__float_as_uint(dinv.z) >> 31) << 8);
-    // 1. the scene-spanning primitives (walls, big lights), wave-uniformly: box pre-test, pairs
-    for (int k = 0; k < p.nbig; ++k) {
-        const int g = p.big[k];
+    // 1. the scene-spanning primitives (walls, big lights), wave-uniformly: box pre-test, pairs.
+    // Camera rays (no lens, tiles whose chunks are 64-pixel spans): the host lists, per span, every primitive whose padded
+    // box reaches into the span's pixel frustum (pt_context.hip); when that list is short it replaces both the
+    // scene-spanning primitives and the walk -- a span of the 256-sphere cloud sees a dozen primitives, not a hierarchy.
+    // (The bounds-checking build walks anyway and reports a leaf that passes its box test without being on the list.)
+    uint32_t list_off = 0u, list_n = 0xFFFFFFFFu;
+    if (FIRST && span != 0xFFFFFFFFu) {
+        const_u32_ptr so = (const_u32_ptr)(uintptr_t)(p.span_off + 2u * span);
+        list_off = so[0];
+        list_n = so[1];                                       // 0xFFFFFFFF: too many to list, walk
+    }
+    const bool listed = list_n != 0xFFFFFFFFu;
+    const int ncand = listed ? (int)list_n : p.nbig;
+    const_u32_ptr lst = (const_u32_ptr)(uintptr_t)(p.span_list + list_off);
+    for (int k = 0; k < ncand; ++k) {
+        const int g = listed ? (int)lst[k] : p.big[k];
         const_u32_ptr hp = (const_u32_ptr)(uintptr_t)(p.prims + g);
         const uint32_t type = hp[0];
-        if (type > 1u) continue;
+        if (type == 2u || type > 3u) continue;                // (MESH geoms have no geometry of their own)
         const_u32_ptr bq = (const_u32_ptr)(uintptr_t)(p.box_world + 8 * g);
         const float x0 = __builtin_fmaf(__uint_as_float(bq[0]), dinv.x, oinv.x), x1 = __builtin_fmaf(__uint_as_float(bq[4]), dinv.x, oinv.x);
         const float y0 = __builtin_fmaf(__uint_as_float(bq[1]), dinv.y, oinv.y), y1 = __builtin_fmaf(__uint_as_float(bq[5]), dinv.y, oinv.y);
@@ -848,7 +861,7 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
     // are queued anyway.)
     // 2. the hierarchy.  Every ray starts with one entry for the root; a step pops the top nb entries (one per lane).
     uint32_t top = 0u;                                        // wave-uniform
-    if (p.nnodes4 > 0) {
+    if (p.nnodes4 > 0 && (!listed || DEBUG_BOUNDS)) {
         const uint64_t vm = __ballot(valid);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
         if (valid) w.stack[rank] = lane | mysigns;            // owner | signs | node 0
@@ -881,8 +894,14 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
         const uint32_t owner = e & 63u, index = (e >> 9) & 0xFFFFFu;
         if (__ballot(leaf) != 0ull) {
             const bool cube = (e & 0x40000000u) != 0u, tri = (e & 0x20000000u) != 0u;
+            if (DEBUG_BOUNDS && listed) {                     // the list already queued the pairs: only check it
+                bool on_list = !leaf;
+                for (uint32_t j = 0; j < list_n; ++j) on_list = on_list || lst[j] == index;
+                if (!on_list) dbgInRange(p, 31, (unsigned long long)index + 1000ull, 0ull);
+            } else {
             pushPairs<FIRST>(p, prims, q, head, tail, leaf && !cube && !tri, leaf && cube, index, lane, owner);
             if (p.ntri > 0) pushTriangles<FIRST>(p, prims, q, thead, ttail, leaf && tri, index, lane, owner);
+            }
         }
         const bool inner = act && (e >> 31) == 0u;
         const uint64_t im = __ballot(inner);
@@ -993,7 +1012,7 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const PrimPad *s_pri
             pq.dir = nullptr;
             pq.po = o;
             pq.pd = d;
-            return nearestHitWalk4<FIRST>(p, p.prims, w4, pq, o, d, want, lane);
+            return nearestHitWalk4<FIRST>(p, p.prims, w4, pq, o, d, want, lane, (FIRST && p.span_off != nullptr) ? primmask : 0xFFFFFFFFu);
         }
         if (GEOM == GEOM_WALK_PAIR) return nearestHitWalkPairs<FIRST>(p, p.prims, s_nodes, pq, o, d, want, lane);
         return nearestHitPairs<FIRST>(p, s_prims, s_nodes, pq, o, d, want, lane, primmask);
@@ -1245,6 +1264,11 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
             while (b0 >= npix) b0 -= npix;                               // the ray's tile-local pixel (at most MAXSLOT - 1 trips)
             const_u32_ptr sm = (const_u32_ptr)(uintptr_t)(p.span_mask + (b0 >> 6));
             primmask = sm[0];
+        }
+        if (FIRST && (GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) && p.span_off != nullptr) {
+            uint32_t b0 = chunk_first_ray;
+            while (b0 >= npix) b0 -= npix;
+            primmask = b0 >> 6;                                           // (the batched walks take the span's number)
         }
         const Hit h = (FIRST && p.lens_radius > 0.0f) ? nearestHit<GEOM, false>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane)
                                                       : nearestHit<GEOM, FIRST>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane, primmask);

@@ -87,6 +87,10 @@ struct pt_ctx {
     float *d_face_n = nullptr;
     float *d_box_eye = nullptr;
     std::vector<float> h_box_eye;          // host copy (the span table of the camera rays is built from it)
+    std::vector<ptd::BvhNode> h_bvh;       // host copies for the per-span primitive lists of the batched walks
+    std::vector<float> h_boxes;            //   padded world boxes (lo.xyz, hi.xyz) by expanded primitive index
+    uint32_t *d_span_off = nullptr, *d_span_list = nullptr;
+    size_t span_off_cap = 0, span_list_cap = 0;
     uint32_t *d_span_mask = nullptr;
     size_t span_mask_cap = 0;
     float *d_box_world = nullptr;
@@ -633,6 +637,9 @@ int configure(pt_ctx *c)
         for (auto &nd : nodes)
             if (nd.prim >= 0) nd.prim |= (ptype[(size_t)nd.prim] == PT_CUBE ? 1 : 0) << 30;
         k.nnodes = (int)nodes.size();
+        c->h_bvh = nodes;
+        c->h_boxes.assign(nP * 6, 0.0f);
+        for (size_t i = 0; i < nP; ++i) for (int a = 0; a < 3; ++a) { c->h_boxes[6 * i + (size_t)a] = boxes[i].lo[a]; c->h_boxes[6 * i + 3 + (size_t)a] = boxes[i].hi[a]; }
         {
             std::vector<float> wide;
             int wdepth = 0;
@@ -764,18 +771,25 @@ int configure(pt_ctx *c)
     }
     k.lbuf = c->d_lbuf;
 
-    // Camera rays of the pair path: which primitives can the 64 pixels of a chunk see at all?  One word per span of 64
-    // tile-local pixels, bit g set unless primitive g's padded box lies wholly outside one of the four side planes of the
-    // span's pixel frustum (grown by a pixel on every side; a span that runs over a row end takes the whole rows) or wholly
-    // behind the eye.  Conservative: a cleared bit only ever drops (ray, primitive) pairs whose box pre-test would fail
-    // in every lane -- the bounds-checking build runs those pre-tests anyway and reports any that passes.  Needs chunks that
-    // are spans (npix % 64 == 0) and rays that start at the eye (no lens).
+    // Camera rays: which primitives can the 64 pixels of a bounce-0 chunk see at all?  A primitive is dropped for a span of
+    // 64 tile-local pixels when its padded box lies wholly outside one of the four side planes of the span's pixel frustum
+    // (grown by a pixel on every side; a span that runs over a row end takes the whole rows) or wholly behind the eye.
+    // Conservative: that only ever drops (ray, primitive) pairs whose box pre-test would fail in every lane -- the
+    // bounds-checking build runs those tests anyway and reports any that passes.  Needs chunks that are spans
+    // (npix % 64 == 0) and rays that start at the eye (no lens).
+    //   pair path (<= 32 primitives): one word per span, bit g = primitive g stays (KParams::span_mask);
+    //   batched walks: per span the list of the primitives that stay -- found by walking the hierarchy with the
+    //   frustum -- which, when it is short, replaces the walk for the camera rays (KParams::span_off / span_list).
     k.span_mask = nullptr;
-    if (cfg.geom == 4 && k.nG <= 32 && k.ntri == 0 && k.eye_cull && !(k.lens_radius > 0.0f) && npix % 64 == 0 &&
-        c->h_box_eye.size() >= (size_t)k.nG * 8) {
+    k.span_off = nullptr;
+    k.span_list = nullptr;
+    const bool spans_ok = k.eye_cull && !(k.lens_radius > 0.0f) && npix % 64 == 0;
+    const bool want_mask = spans_ok && cfg.geom == 4 && k.nG <= 32 && k.ntri == 0 && c->h_box_eye.size() >= (size_t)k.nG * 8;
+    const bool want_lists = spans_ok && (cfg.geom == 6 || cfg.geom == 7) && c->h_boxes.size() >= (size_t)k.nG * 6 && k.nG <= 65536;
+    if (want_mask || want_lists) {
         const int nspan = npix / 64;
-        std::vector<uint32_t> tab((size_t)nspan, 0u);
         const double ex = k.eye[0], ey = k.eye[1], ez = k.eye[2];
+        const double eye3[3] = {ex, ey, ez};
         const double vw[3] = {(double)k.M[0] - ex, (double)k.M[1] - ey, (double)k.M[2] - ez};
         auto gpix = [&](uint32_t pl) -> uint32_t {
             if (k.strip_span == 0u) return pl + k.pix_offset;
@@ -785,7 +799,9 @@ int configure(pt_ctx *c)
         auto dirOf = [&](double sx, double sy, double *o3) {
             for (int a = 0; a < 3; ++a) o3[a] = vw[a] + (1.0 - 2.0 * sx) * (double)k.H[a] + (1.0 - 2.0 * sy) * (double)k.V[a];
         };
-        for (int sp = 0; sp < nspan; ++sp) {
+        struct Frustum { double nrm[4][3], cc[3], lcc; bool planes_ok, narrow; };
+        auto frustumOf = [&](int sp) -> Frustum {
+            Frustum f;
             const uint32_t g0 = gpix((uint32_t)sp * 64u), g1 = gpix((uint32_t)sp * 64u + 63u);
             const int y0 = (int)(g0 / (uint32_t)W), y1 = (int)(g1 / (uint32_t)W);
             int xa = (int)(g0 % (uint32_t)W), xb = (int)(g1 % (uint32_t)W);
@@ -793,57 +809,128 @@ int configure(pt_ctx *c)
             const int ya = y0 < y1 ? y0 : y1, yb = y0 < y1 ? y1 : y0;
             const double sx0 = ((double)xa - 1.0) / (double)k.resx, sx1 = ((double)xb + 2.0) / (double)k.resx;
             const double sy0 = ((double)ya - 1.0) / (double)k.resy, sy1 = ((double)yb + 2.0) / (double)k.resy;
-            double cn[4][3], cc[3];
+            double cn[4][3];
             dirOf(sx0, sy0, cn[0]); dirOf(sx1, sy0, cn[1]); dirOf(sx1, sy1, cn[2]); dirOf(sx0, sy1, cn[3]);
-            dirOf(0.5 * (sx0 + sx1), 0.5 * (sy0 + sy1), cc);
-            double nrm[4][3];
-            bool planes_ok = true;
+            dirOf(0.5 * (sx0 + sx1), 0.5 * (sy0 + sy1), f.cc);
+            f.planes_ok = true;
             for (int e = 0; e < 4; ++e) {
                 const double *a3 = cn[e], *b3 = cn[(e + 1) & 3];
-                double n3[3] = {a3[1] * b3[2] - b3[1] * a3[2], a3[2] * b3[0] - b3[2] * a3[0], a3[0] * b3[1] - b3[0] * a3[1]};
+                const double n3[3] = {a3[1] * b3[2] - b3[1] * a3[2], a3[2] * b3[0] - b3[2] * a3[0], a3[0] * b3[1] - b3[0] * a3[1]};
                 const double len = sqrt(n3[0] * n3[0] + n3[1] * n3[1] + n3[2] * n3[2]);
-                if (!(len > 1e-12)) { planes_ok = false; break; }
-                const double s = (n3[0] * cc[0] + n3[1] * cc[1] + n3[2] * cc[2]) > 0.0 ? -1.0 / len : 1.0 / len;    // outward: the centre is inside
-                for (int a = 0; a < 3; ++a) nrm[e][a] = n3[a] * s;
+                if (!(len > 1e-12)) { f.planes_ok = false; break; }
+                const double sg = (n3[0] * f.cc[0] + n3[1] * f.cc[1] + n3[2] * f.cc[2]) > 0.0 ? -1.0 / len : 1.0 / len;    // outward: the centre is inside
+                for (int a = 0; a < 3; ++a) f.nrm[e][a] = n3[a] * sg;
             }
             // "behind the eye" only when every corner direction is within 60 degrees of the centre direction
-            const double lcc = sqrt(cc[0] * cc[0] + cc[1] * cc[1] + cc[2] * cc[2]);
-            bool narrow = planes_ok && lcc > 1e-12;
-            for (int e = 0; e < 4 && narrow; ++e) {
+            f.lcc = sqrt(f.cc[0] * f.cc[0] + f.cc[1] * f.cc[1] + f.cc[2] * f.cc[2]);
+            f.narrow = f.planes_ok && f.lcc > 1e-12;
+            for (int e = 0; e < 4 && f.narrow; ++e) {
                 const double l = sqrt(cn[e][0] * cn[e][0] + cn[e][1] * cn[e][1] + cn[e][2] * cn[e][2]);
-                if (!((cn[e][0] * cc[0] + cn[e][1] * cc[1] + cn[e][2] * cc[2]) > 0.5 * l * lcc)) narrow = false;
+                if (!((cn[e][0] * f.cc[0] + cn[e][1] * f.cc[1] + cn[e][2] * f.cc[2]) > 0.5 * l * f.lcc)) f.narrow = false;
             }
-            uint32_t m = 0u;
-            for (int g = 0; g < k.nG; ++g) {
-                const float *bx = &c->h_box_eye[(size_t)g * 8];
-                bool out = false;
-                double scale = 1.0;
-                for (int a = 0; a < 3; ++a) scale += fabs((double)bx[a]) + fabs((double)bx[4 + a]);
-                if (planes_ok) {
-                    for (int e = 0; e < 4 && !out; ++e) {
-                        double vmin = 0.0;          // the box corner deepest inside this plane
-                        for (int a = 0; a < 3; ++a) { const double lo = nrm[e][a] * (double)bx[a], hi = nrm[e][a] * (double)bx[4 + a]; vmin += lo < hi ? lo : hi; }
-                        if (vmin > 1e-5 * scale) out = true;
-                    }
-                    if (!out && narrow) {
-                        double vmax = 0.0;
-                        for (int a = 0; a < 3; ++a) { const double lo = cc[a] * (double)bx[a], hi = cc[a] * (double)bx[4 + a]; vmax += lo > hi ? lo : hi; }
-                        if (vmax < -1e-5 * scale * lcc) out = true;
-                    }
+            return f;
+        };
+        // box given relative to the eye
+        auto outside = [&](const Frustum &f, const double *lo, const double *hi) -> bool {
+            if (!f.planes_ok) return false;
+            double scale = 1.0;
+            for (int a = 0; a < 3; ++a) scale += fabs(lo[a]) + fabs(hi[a]);
+            for (int e = 0; e < 4; ++e) {
+                double vmin = 0.0;                  // the box corner deepest inside this plane
+                for (int a = 0; a < 3; ++a) { const double x = f.nrm[e][a] * lo[a], y = f.nrm[e][a] * hi[a]; vmin += x < y ? x : y; }
+                if (vmin > 1e-5 * scale) return true;
+            }
+            if (f.narrow) {
+                double vmax = 0.0;
+                for (int a = 0; a < 3; ++a) { const double x = f.cc[a] * lo[a], y = f.cc[a] * hi[a]; vmax += x > y ? x : y; }
+                if (vmax < -1e-5 * scale * f.lcc) return true;
+            }
+            return false;
+        };
+        if (want_mask) {
+            std::vector<uint32_t> tab((size_t)nspan, 0u);
+            for (int sp = 0; sp < nspan; ++sp) {
+                const Frustum f = frustumOf(sp);
+                uint32_t m = 0u;
+                for (int g = 0; g < k.nG; ++g) {
+                    const float *bx = &c->h_box_eye[(size_t)g * 8];
+                    const double lo[3] = {bx[0], bx[1], bx[2]}, hi[3] = {bx[4], bx[5], bx[6]};
+                    if (!outside(f, lo, hi)) m |= 1u << g;
                 }
-                if (!out) m |= 1u << g;
+                tab[(size_t)sp] = m;
             }
-            tab[(size_t)sp] = m;
+            if (c->span_mask_cap < tab.size()) {
+                if (c->d_span_mask) (void)hipFree(c->d_span_mask);
+                c->d_span_mask = nullptr; c->span_mask_cap = 0;
+                HIP_TRY(hipMalloc((void **)&c->d_span_mask, tab.size() * sizeof(uint32_t)));
+                c->span_mask_cap = tab.size();
+            }
+            HIP_TRY(hipStreamSynchronize(c->stream));          // (launches of the previous configuration may still read the table)
+            HIP_TRY(hipMemcpy(c->d_span_mask, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            k.span_mask = c->d_span_mask;
         }
-        if (c->span_mask_cap < tab.size()) {
-            if (c->d_span_mask) (void)hipFree(c->d_span_mask);
-            c->d_span_mask = nullptr; c->span_mask_cap = 0;
-            HIP_TRY(hipMalloc((void **)&c->d_span_mask, tab.size() * sizeof(uint32_t)));
-            c->span_mask_cap = tab.size();
+        if (want_lists) {
+            const uint32_t LIST_MAX = 40;                      // longer than this: the walk is the better deal
+            std::vector<uint32_t> off((size_t)nspan * 2, 0u), lst;
+            lst.reserve((size_t)nspan * 12);
+            const std::vector<ptd::BvhNode> &bn = c->h_bvh;
+            std::vector<uint32_t> cand;
+            auto relBox = [&](const float *lo, const float *hi, double *rl, double *rh) {
+                for (int a = 0; a < 3; ++a) {
+                    const double l = (double)lo[a] - eye3[a], h = (double)hi[a] - eye3[a];
+                    const double pad = 1e-6 * (fabs(l) + fabs(h) + fabs(eye3[a])) + 1e-6;
+                    rl[a] = l - pad; rh[a] = h + pad;
+                }
+            };
+            for (int sp = 0; sp < nspan; ++sp) {
+                const Frustum f = frustumOf(sp);
+                cand.clear();
+                double rl[3], rh[3];
+                for (int b = 0; b < k.nbig; ++b) {
+                    const size_t g = (size_t)k.big[b];
+                    relBox(&c->h_boxes[6 * g], &c->h_boxes[6 * g + 3], rl, rh);
+                    if (!outside(f, rl, rh)) cand.push_back((uint32_t)g);
+                }
+                bool too_many = false;
+                for (uint32_t i = 0; i < (uint32_t)k.nnodes && !too_many;) {
+                    const ptd::BvhNode &nd = bn[i];
+                    relBox(nd.lo, nd.hi, rl, rh);
+                    if (outside(f, rl, rh)) { i = nd.skip; continue; }
+                    if (nd.prim >= 0) {
+                        cand.push_back((uint32_t)nd.prim & 0x3FFFFFFFu);
+                        if (cand.size() > LIST_MAX) too_many = true;
+                    }
+                    i = i + 1u;
+                }
+                off[2 * (size_t)sp] = (uint32_t)lst.size();
+                if (too_many) off[2 * (size_t)sp + 1] = 0xFFFFFFFFu;
+                else { off[2 * (size_t)sp + 1] = (uint32_t)cand.size(); lst.insert(lst.end(), cand.begin(), cand.end()); }
+            }
+            if (lst.empty()) lst.push_back(0u);
+            if (c->span_off_cap < off.size()) {
+                if (c->d_span_off) (void)hipFree(c->d_span_off);
+                c->d_span_off = nullptr; c->span_off_cap = 0;
+                HIP_TRY(hipMalloc((void **)&c->d_span_off, off.size() * sizeof(uint32_t)));
+                c->span_off_cap = off.size();
+            }
+            if (c->span_list_cap < lst.size()) {
+                if (c->d_span_list) (void)hipFree(c->d_span_list);
+                c->d_span_list = nullptr; c->span_list_cap = 0;
+                HIP_TRY(hipMalloc((void **)&c->d_span_list, lst.size() * sizeof(uint32_t)));
+                c->span_list_cap = lst.size();
+            }
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipMemcpy(c->d_span_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(c->d_span_list, lst.data(), lst.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            k.span_off = c->d_span_off;
+            k.span_list = c->d_span_list;
+            if (getenv("PT_DEBUG_CLOCK")) {
+                size_t walked = 0;
+                for (int sp = 0; sp < nspan; ++sp) walked += off[2 * (size_t)sp + 1] == 0xFFFFFFFFu;
+                fprintf(stderr, "[ptamd] camera-ray lists: %d spans, %.1f primitives per listed span, %zu spans walk\n", nspan,
+                        (double)lst.size() / (double)(nspan - (int)walked > 0 ? nspan - (int)walked : 1), walked);
+            }
         }
-        HIP_TRY(hipStreamSynchronize(c->stream));          // (launches of the previous configuration may still read the table)
-        HIP_TRY(hipMemcpy(c->d_span_mask, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        k.span_mask = c->d_span_mask;
     }
 
     // ray pools: 2 x nshard segments of `segcap` rays x 40 B, carved from one allocation.  A segment must hold

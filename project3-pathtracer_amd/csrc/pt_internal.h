@@ -73,6 +73,8 @@ struct KParams {
     int eye_cull;          // 1 = camera-ray waves skip primitives outside their boxes (box_eye), ablation switch
     const float *box_world; // per primitive: padded world box (lo.xyz,0)(hi.xyz,0): per-lane pre-test of the pair queue
     const float *box_eye;  // per primitive: padded world box minus the eye, (lo.xyz,0)(hi.xyz,0): wave cull of camera rays
+    const uint32_t *span_off;   // batched walks, camera rays: per span (offset, count) into span_list; count 0xFFFFFFFF = walk (nullptr: no lists)
+    const uint32_t *span_list;  // primitive indices
     const uint32_t *span_mask;  // pair path, camera rays: per 64 tile-local pixels, bit g = primitive g can be seen from them (nullptr: no table)
     const float *mats;     // M_PLANES planes of nM floats
     float *image;          // tile framebuffer, fp32 RGB packed (12 B/pixel)

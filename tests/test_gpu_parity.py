@@ -433,7 +433,7 @@ def test_camera_span_table_is_conservative(pkg, seed):
     count is a multiple of 64 and there is no lens) must only drop pairs that would miss -- random cameras (inside
     objects, narrow and very wide fields of view, rolled), random TRS primitives, whole frames, bands and strip tiles."""
     rng = np.random.default_rng(4200 + seed)
-    n_prims = [3, 9, 20, 32][seed % 4]
+    n_prims = [3, 9, 20, 32][seed % 4] if seed % 2 else [60, 150, 24, 300][(seed // 2) % 4]
     geoms, mats, eye, view, up, _ = _random_scene(7000 + seed, n_prims)
     W, H = [(64, 48), (96, 64), (128, 40), (192, 8), (32, 30)][seed % 5]
     if (W * H) % 64:
@@ -445,9 +445,12 @@ def test_camera_span_table_is_conservative(pkg, seed):
     cam = O.make_camera(W, H, eye * (3.0 if seed % 3 == 0 else 1.0), view, up, fovy)      # every third camera outside the cluster
     ref, live = O.render(ga, len(geoms), ma, len(mats), cam, depth, iters=iters, seed=seed)
     tiles = [dict(), dict(geom_path=5)]
+    if seed % 2 == 0:
+        tiles = [dict(), dict(geom_path=7), dict(geom_path=8)]      # the batched walks take per-span primitive lists
     if H % 16 == 0:
-        tiles.append(dict(geom_path=5, strip_rows=8, strip_world=2, strip_rank=seed % 2))
-        tiles.append(dict(geom_path=5, row_begin=H // 2, row_end=H))
+        gp = 5 if seed % 2 else 7
+        tiles.append(dict(geom_path=gp, strip_rows=8, strip_world=2, strip_rank=seed % 2))
+        tiles.append(dict(geom_path=gp, row_begin=H // 2, row_end=H))
     for opts in tiles:
         with pkg.Renderer(0) as r:
             r.set_options(depth=depth, seed=seed, **opts)
@@ -740,6 +743,39 @@ def test_triangle_meshes_match_oracle(pkg, geom_path):
     c, lc = O.render(osc.geoms, osc.n_objects, osc.mats, osc.n_materials, osc.camera, 9, iters=3, meshes=osc.meshes)
     check(g, c, lg, [int(x) for x in lc], f"triangle meshes geom_path={geom_path}")
     assert sum(lg) > 0
+
+
+@pytest.mark.parametrize("geom_path", [0, 1, 7, 8])
+def test_scene_spanning_triangles(pkg, geom_path, tmp_path):
+    """A mesh whose two triangles span the room: they join the scene-spanning primitives that the batched walks test
+    before the hierarchy (that loop once skipped every record that was not a sphere or a cube), and they are on most
+    spans' camera-ray lists."""
+    import shutil
+    shutil.copytree(os.path.join(SCENES, "meshes"), tmp_path / "meshes")
+    (tmp_path / "meshes" / "quad.obj").write_text("v -0.5 0 -0.5\nv 0.5 0 -0.5\nv 0.5 0 0.5\nv -0.5 0 0.5\nf 1 2 3 4\n")
+    text = open(os.path.join(SCENES, "mesh_cornell.txt")).read().rstrip("\n")
+    text += "\n\nOBJECT 10\nmeshes/quad.obj\nmaterial 1\nframe 0\nTRANS 0 3.5 -1\nROTAT 25 0 12\nSCALE 9 9 9\n"
+    path = tmp_path / "big_quad.txt"
+    path.write_text(text)
+    W, H, depth, iters = 128, 96, 6, 2
+    sc = pkg.SceneFile(str(path), 1)
+    sc.set_resolution(W, H)
+    with pkg.Renderer(0) as r:
+        r.set_options(depth=depth, geom_path=geom_path)
+        r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
+        r.set_meshes(sc.meshes)
+        r.set_camera(sc.camera)
+        r.clear_image()
+        r.render(1, iters)
+        g = r.download_image()
+        st = r.stats()
+    osc = O.LoadedScene(str(path), 1)
+    osc.set_resolution(W, H)
+    c, lc = O.render(osc.geoms, osc.n_objects, osc.mats, osc.n_materials, osc.camera, depth, iters=iters, meshes=osc.meshes)
+    check(g, c, [int(x) for x in st.live_in[:depth]], [int(x) for x in lc], f"scene-spanning triangles geom_path={geom_path}")
+    base, _ = O.render(osc.geoms, osc.n_objects - 1, osc.mats, osc.n_materials, osc.camera, depth, iters=iters,
+                       meshes={i: m for i, m in osc.meshes.items() if i < osc.n_objects - 1})
+    assert not np.array_equal(base, c)                    # the quad is in the picture
 
 
 def test_triangle_meshes_with_options_and_errors(pkg):
