@@ -23,10 +23,14 @@ def run(case, override):
     if rng.random() < 0.3:
         mats[3].absorptionCoefficient = O.v3(*rng.uniform(0, 3, 3))
     W, H = int(rng.integers(1, 90)), int(rng.integers(1, 60))
+    if case % 3 == 0:
+        W = int(rng.choice([8, 16, 24, 32, 40, 64, 72, 88, 128]))
+        step = 64 // int(np.gcd(W, 64))
+        H = step * int(rng.integers(1, max(2, 56 // step)))
     depth = int(rng.integers(1, 10))
     iters = int(rng.integers(1, 5))
     opts = dict(rr_start=int(rng.integers(-1, depth)), seed=int(rng.integers(0, 1000)))
-    gopts = dict(geom_path=int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7])), batch=int(rng.choice([0, 1, 2, 3, 7, 16])))
+    gopts = dict(geom_path=int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8] if case % 3 == 0 else [0, 1, 2, 3, 4, 5, 6, 7])), batch=int(rng.choice([0, 1, 2, 3, 7, 16])))
     if rng.random() < 0.4:
         opts["direct_light"] = 1
     if rng.random() < 0.4:
