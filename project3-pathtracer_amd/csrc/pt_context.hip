@@ -783,7 +783,7 @@ int configure(pt_ctx *c)
     k.span_mask = nullptr;
     k.span_off = nullptr;
     k.span_list = nullptr;
-    const bool spans_ok = k.eye_cull && !(k.lens_radius > 0.0f) && npix % 64 == 0;
+    const bool spans_ok = k.eye_cull && !(k.lens_radius > 0.0f) && npix % 64 == 0 && npix / 64 <= (1 << 21);    // (host work: <= 2 M spans, a 134 Mpx tile)
     const bool want_mask = spans_ok && cfg.geom == 4 && k.nG <= 32 && k.ntri == 0 && c->h_box_eye.size() >= (size_t)k.nG * 8;
     const bool want_lists = spans_ok && (cfg.geom == 6 || cfg.geom == 7) && c->h_boxes.size() >= (size_t)k.nG * 6 && k.nG <= 65536;
     if (want_mask || want_lists) {
