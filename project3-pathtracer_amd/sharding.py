@@ -64,11 +64,13 @@ def gather_strips(local_tile, height, world, rank, strip_rows=STRIP_ROWS, dist=N
 
 
 def weak_scaled_frame(width, height, world):
-    """Frame for `world` GPUs at fixed per-GPU pixel count and fixed aspect (world=4 -> 2x in both dimensions)."""
+    """Frame for `world` GPUs at fixed per-GPU pixel count and fixed aspect (world=4 -> 2x in both dimensions).  The height
+    is a multiple of STRIP_ROWS, so every rank's strips are whole and its pixel count a multiple of 64 (the renderer's
+    camera-ray tables need chunks that are 64-pixel spans)."""
     if world == 1:
         return width, height
     s = float(world) ** 0.5
-    return int(round(width * s / 16.0)) * 16, int(round(height * s / 2.0)) * 2
+    return int(round(width * s / 16.0)) * 16, int(round(height * s / STRIP_ROWS)) * STRIP_ROWS
 
 
 def scaled_frame(width, height, world, scaling="weak"):

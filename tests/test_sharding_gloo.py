@@ -130,6 +130,10 @@ def test_band_partition_properties():
     assert sharding.weak_scaled_frame(1920, 1080, 4) == (3840, 2160)          # BASELINE configs[3]
     w8, h8 = sharding.weak_scaled_frame(1920, 1080, 8)
     assert abs(w8 * h8 / (8 * 1920 * 1080) - 1) < 0.01
+    for world in (2, 4, 8):          # whole strips on every rank: tile pixel counts are multiples of 64
+        w, h = sharding.weak_scaled_frame(1920, 1080, world)
+        assert h % sharding.STRIP_ROWS == 0 and w % 16 == 0
+        assert all((sharding.strip_local_rows(h, world, r) * w) % 64 == 0 for r in range(world))
 
 
 def test_strong_scaling_keeps_the_frame():
