@@ -1256,14 +1256,20 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
         bool alive = false;
         const unsigned long long c1 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
         // camera rays share the eye (host-side eye transforms and eye-relative boxes) unless a lens spreads their origins
-        // camera rays of the pair path: which primitives the chunk's 64 pixels can see (host-built table, one word per 64
-        // tile-local pixels; the host only supplies it when every chunk is such a span: npix % 64 == 0, no lens)
+        // camera rays of the pair path: which primitives the chunk's 64 pixels can see (host-built table, one word per span
+        // of 64 tile-local pixels, no lens).  A chunk is one span when npix % 64 == 0; else it lies across two of them
+        // and, where it runs over the end of an iteration slot, across the tile's first span as well.
         uint32_t primmask = 0xFFFFFFFFu;
         if (FIRST && GEOM == GEOM_PAIR && p.span_mask != nullptr) {
-            uint32_t b0 = chunk_first_ray;                                // wave-uniform
-            while (b0 >= npix) b0 -= npix;                               // the ray's tile-local pixel (at most MAXSLOT - 1 trips)
-            const_u32_ptr sm = (const_u32_ptr)(uintptr_t)(p.span_mask + (b0 >> 6));
-            primmask = sm[0];
+            const_u32_ptr sm = (const_u32_ptr)(uintptr_t)p.span_mask;
+            if (npix <= 64u) primmask = sm[0];                            // one span is the whole tile
+            else {
+                uint32_t b0 = chunk_first_ray;                            // wave-uniform
+                while (b0 >= npix) b0 -= npix;                           // its tile-local pixel (at most MAXSLOT - 1 trips)
+                const uint32_t e = b0 + 63u;
+                primmask = sm[b0 >> 6] | sm[(e < npix ? e : npix - 1u) >> 6];
+                if (e >= npix) primmask |= sm[0];
+            }
         }
         if (FIRST && (GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) && p.span_off != nullptr) {
             uint32_t b0 = chunk_first_ray;

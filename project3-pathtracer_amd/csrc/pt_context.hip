@@ -775,19 +775,19 @@ int configure(pt_ctx *c)
     // 64 tile-local pixels when its padded box lies wholly outside one of the four side planes of the span's pixel frustum
     // (grown by a pixel on every side; a span that runs over a row end takes the whole rows) or wholly behind the eye.
     // Conservative: that only ever drops (ray, primitive) pairs whose box pre-test would fail in every lane -- the
-    // bounds-checking build runs those tests anyway and reports any that passes.  Needs chunks that are spans
-    // (npix % 64 == 0) and rays that start at the eye (no lens).
+    // bounds-checking build runs those tests anyway and reports any that passes.  Needs rays that start at the eye (no
+    // lens); the lists also need chunks that are spans (npix % 64 == 0), the table copes with chunks across spans.
     //   pair path (<= 32 primitives): one word per span, bit g = primitive g stays (KParams::span_mask);
     //   batched walks: per span the list of the primitives that stay -- found by walking the hierarchy with the
     //   frustum -- which, when it is short, replaces the walk for the camera rays (KParams::span_off / span_list).
     k.span_mask = nullptr;
     k.span_off = nullptr;
     k.span_list = nullptr;
-    const bool spans_ok = k.eye_cull && !(k.lens_radius > 0.0f) && npix % 64 == 0 && npix / 64 <= (1 << 21);    // (host work: <= 2 M spans, a 134 Mpx tile)
+    const bool spans_ok = k.eye_cull && !(k.lens_radius > 0.0f) && npix / 64 <= (1 << 21);    // (host work: <= 2 M spans, a 134 Mpx tile)
     const bool want_mask = spans_ok && cfg.geom == 4 && k.nG <= 32 && k.ntri == 0 && c->h_box_eye.size() >= (size_t)k.nG * 8;
-    const bool want_lists = spans_ok && (cfg.geom == 6 || cfg.geom == 7) && c->h_boxes.size() >= (size_t)k.nG * 6 && k.nG <= 65536;
+    const bool want_lists = spans_ok && npix % 64 == 0 && (cfg.geom == 6 || cfg.geom == 7) && c->h_boxes.size() >= (size_t)k.nG * 6 && k.nG <= 65536;
     if (want_mask || want_lists) {
-        const int nspan = npix / 64;
+        const int nspan = (npix + 63) / 64;                  // (the last one may be short; the lists need npix % 64 == 0)
         const double ex = k.eye[0], ey = k.eye[1], ez = k.eye[2];
         const double eye3[3] = {ex, ey, ez};
         const double vw[3] = {(double)k.M[0] - ex, (double)k.M[1] - ey, (double)k.M[2] - ez};
@@ -802,7 +802,8 @@ int configure(pt_ctx *c)
         struct Frustum { double nrm[4][3], cc[3], lcc; bool planes_ok, narrow; };
         auto frustumOf = [&](int sp) -> Frustum {
             Frustum f;
-            const uint32_t g0 = gpix((uint32_t)sp * 64u), g1 = gpix((uint32_t)sp * 64u + 63u);
+            const uint32_t pl1 = (uint32_t)sp * 64u + 63u < (uint32_t)npix ? (uint32_t)sp * 64u + 63u : (uint32_t)npix - 1u;
+            const uint32_t g0 = gpix((uint32_t)sp * 64u), g1 = gpix(pl1);
             const int y0 = (int)(g0 / (uint32_t)W), y1 = (int)(g1 / (uint32_t)W);
             int xa = (int)(g0 % (uint32_t)W), xb = (int)(g1 % (uint32_t)W);
             if (y0 != y1) { xa = 0; xb = W - 1; }
