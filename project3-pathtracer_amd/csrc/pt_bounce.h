@@ -522,13 +522,14 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
     // less than 1.2e-6 |o|, far inside the boxes' padding
     const f3 oinv = FIRST ? mk(0, 0, 0) : mk(-(o.x * dinv.x), -(o.y * dinv.y), -(o.z * dinv.z));
     for (int g = 0; g < p.nG; ++g) {
+        // camera rays: the host's table says which primitives the 64 pixels of this chunk can see at all (primmask, bit g;
+        // all ones without a table).  The bounds-checking build runs the test anyway and reports a pair that passes.
+        // (First thing in the loop: a culled primitive then costs three scalar instructions, not a wait for its type.)
+        const bool culled = FIRST && ((primmask >> ((uint32_t)g & 31u)) & 1u) == 0u;
+        if (culled && !DEBUG_BOUNDS) continue;
         const_u32_ptr hp = (const_u32_ptr)(uintptr_t)(p.prims + g);
         const uint32_t type = hp[0];
         if (type > 1u) continue;                             // MESH: never has geometry
-        // camera rays: the host's table says which primitives the 64 pixels of this chunk can see at all (primmask, bit g;
-        // all ones without a table).  The bounds-checking build runs the test anyway and reports a pair that passes.
-        const bool culled = FIRST && ((primmask >> ((uint32_t)g & 31u)) & 1u) == 0u;
-        if (culled && !DEBUG_BOUNDS) continue;
         // padded world box of the primitive against this lane's ray (camera rays: box relative to the shared eye), through
         // an LDS broadcast read: VGPR operands keep the six fma at the full VALU rate (SGPR operands halve it)
         const float4 lo4 = s_boxes[2 * g], hi4 = s_boxes[2 * g + 1];
