@@ -891,9 +891,11 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
         if (fifo) qh = wrap(qh + nb);
         top -= nb;
         if (DEBUG_BVH) { dbg_steps++; dbg_entries += nb; }
-        const bool leaf = act && (e >> 31) != 0u;
+        // lane masks straight from the compares (an inactive lane holds e = 0: neither leaf nor, below, inner)
+        const uint64_t leafm = __builtin_amdgcn_sicmp((int)e, 0, 40 /* ICMP_SLT: bit 31 set */);
+        const bool leaf = __builtin_amdgcn_inverse_ballot_w64(leafm);
         const uint32_t owner = e & 63u, index = (e >> 9) & 0xFFFFFu;
-        if (__ballot(leaf) != 0ull) {
+        if (leafm != 0ull) {
             const bool cube = (e & 0x40000000u) != 0u, tri = (e & 0x20000000u) != 0u;
             if (DEBUG_BOUNDS && listed) {                     // the list already queued the pairs: only check it
                 bool on_list = !leaf;
@@ -904,8 +906,8 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
             if (p.ntri > 0) pushTriangles<FIRST>(p, prims, q, thead, ttail, leaf && tri, index, lane, owner);
             }
         }
-        const bool inner = act && (e >> 31) == 0u;
-        const uint64_t im = __ballot(inner);
+        const uint64_t im = (nb >= 64u ? ~0ull : ((1ull << nb) - 1ull)) & ~leafm;      // active and not a leaf
+        const bool inner = __builtin_amdgcn_inverse_ballot_w64(im);
         if (im == 0ull) continue;
         // the owner's (1/d, -o/d) out of ITS registers (every lane of the wave is here: uniform control flow)
         const int oaddr = (int)(owner << 2);
