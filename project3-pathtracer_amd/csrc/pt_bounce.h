@@ -896,14 +896,18 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
         const bool leaf = __builtin_amdgcn_inverse_ballot_w64(leafm);
         const uint32_t owner = e & 63u, index = (e >> 9) & 0xFFFFFu;
         if (leafm != 0ull) {
-            const bool cube = (e & 0x40000000u) != 0u, tri = (e & 0x20000000u) != 0u;
+            // child words: 100x.. sphere, 110x.. cube, 101x.. triangle leaf
+            const uint32_t cls = e >> 29;
+            const bool sph = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_uicmp(cls, 4u, 32 /* ICMP_EQ */));
+            const bool cube = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_uicmp(cls, 6u, 32));
+            const bool tri = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_uicmp(cls, 5u, 32));
             if (DEBUG_BOUNDS && listed) {                     // the list already queued the pairs: only check it
                 bool on_list = !leaf;
                 for (uint32_t j = 0; j < list_n; ++j) on_list = on_list || lst[j] == index;
                 if (!on_list) dbgInRange(p, 31, (unsigned long long)index + 1000ull, 0ull);
             } else {
-            pushPairs<FIRST>(p, prims, q, head, tail, leaf && !cube && !tri, leaf && cube, index, lane, owner);
-            if (p.ntri > 0) pushTriangles<FIRST>(p, prims, q, thead, ttail, leaf && tri, index, lane, owner);
+            pushPairs<FIRST>(p, prims, q, head, tail, sph, cube, index, lane, owner);
+            if (p.ntri > 0) pushTriangles<FIRST>(p, prims, q, thead, ttail, tri, index, lane, owner);
             }
         }
         const uint64_t im = (nb >= 64u ? ~0ull : ((1ull << nb) - 1ull)) & ~leafm;      // active and not a leaf
