@@ -14,13 +14,16 @@ BASELINE.json configs[1]: the bundled sampleScene at 1920x1080, 8 bounces, diffu
 its 256 spp.  For N>1 (launched by torch.distributed.run, one rank per GPU) the frame grows with N at fixed
 aspect and camera (N=4 is configs[3]'s 3840x2160) and every rank renders one band of rows of it: per-GPU work
 is fixed ("weak"), no collective on the data path during rendering, and ONE RCCL gather of framebuffer tiles to
-rank 0 inside the timed region (the path's only real exchange step): the previous frame's tiles, enqueued on RCCL's
-stream before the K steps go to the render stream, as a renderer in steady state overlaps them.
+rank 0 inside the timed region (the path's only real exchange step): the tiles of the frame the K steps just rendered,
+behind them (`value`).  A second region times the steady-state variant -- the previous frame's tiles gathered on RCCL's
+stream WHILE the next K steps render -- and is reported beside it as `value_pipelined_gather`.
 
 Prints ONE JSON line (rank 0).  `value` = ray-bounces of all ranks / wall time, in Mray-bounces/s, with
 inputs resident in HBM before the timed region.  The `roofline` block prices the dominant kernel (k_bounce)
-against HBM: algorithmic bytes / HIP-event kernel time.  `cpu_baseline` times the CPU oracle
-on a bounded sample of the same workload on this box's host cores (rank 0, N=1 only).
+against HBM: algorithmic bytes of the timed region's launches / the HIP-event time of the timed
+region on the render stream (two launch sequences are in flight, so a launch's own duration overlaps its
+neighbour's: the block also carries the kernel-alone figure from per-launch events).  `cpu_baseline` times the CPU
+oracle on a bounded sample of the same workload on this box's host cores (rank 0, N=1 only).
 """
 import argparse
 import ctypes as C
@@ -73,6 +76,8 @@ def parse():
     ap.add_argument("--geom-path", type=int, default=0)
     ap.add_argument("--no-compaction", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="iterations in flight per launch sequence (0 = library default)")
+    ap.add_argument("--sequences", type=int, default=0, help="launch sequences in flight (0 = library default 2)")
+    ap.add_argument("--dist-timeout", type=float, default=120.0, help="N > 1: seconds a rank waits for the others before giving up")
     ap.add_argument("--compaction", type=int, default=1, help="1 per-wave sharded (default), 2 workgroup scan, 0 off")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--direct-light", action="store_true", help="explicit light sampling (not the headline workload)")
@@ -164,10 +169,17 @@ def main():
     dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=dev)
+        import datetime
+        # a missing rank must not hang the run until the driver's limit: the rendezvous gives up after --dist-timeout
+        # seconds and this rank exits non-zero (a fresh process is the retry; nothing here re-executes itself)
+        try:
+            if rehearsal:
+                dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=args.dist_timeout))
+            else:
+                dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=args.dist_timeout))
+        except Exception as e:      # noqa: BLE001
+            print(f"bench.py: rank {rank}/{world}: init_process_group gave up after {args.dist_timeout:.0f} s: {e}", file=sys.stderr, flush=True)
+            sys.exit(3)
 
     rotat = pkg.ROTAT_DEGREES if args.rotat == "degrees" else pkg.ROTAT_RADIANS
     scene_path = os.path.join(ROOT, "scenes", args.scene)
@@ -196,7 +208,7 @@ def main():
                   compaction=0 if args.no_compaction else args.compaction, batch=args.batch, use_graph=0 if args.no_graph else 1,
                   row_begin=r0 if (world > 1 and not strips) else 0, row_end=r1 if (world > 1 and not strips) else 0,
                   strip_rows=sharding.STRIP_ROWS if strips else 0, strip_world=world if strips else 0,
-                  strip_rank=rank if strips else 0, direct_light=1 if args.direct_light else 0)
+                  strip_rank=rank if strips else 0, direct_light=1 if args.direct_light else 0, sequences=args.sequences)
     r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
     r.set_camera(sc.camera)
     r.bind_image(fb.data_ptr())
@@ -220,7 +232,11 @@ def main():
             barrier()
             torch.cuda.synchronize(dev)
 
-    # warmup (untimed): also captures the per-iteration hipGraph
+    def tile_checksum(t):
+        # order-independent: the bit patterns summed as integers (a float sum depends on the reduction's shape)
+        return int(t.contiguous().view(torch.int32).to(torch.int64).sum().item())
+
+    # warmup (untimed): also captures the per-sequence hipGraphs
     t_w = time.perf_counter()
     if args.warmup > 0:
         r.render(1, args.warmup)
@@ -232,14 +248,26 @@ def main():
         sync()
         gather_ms = (time.perf_counter() - t_g) * 1e3
     sync()
+    next_iter = args.warmup + 1
+    # cold figure (N = 1, reported as `value_cold`, never as `value`): the same K steps right behind the W warm-up steps,
+    # before the GPU clock has settled -- what the first ~100 ms of a real render run at
+    value_cold = None
+    if world == 1 and args.settle_ms > 0:
+        r.reset_stats()
+        sync()
+        t0 = time.perf_counter()
+        r.render(next_iter, args.steps)
+        r.synchronize()
+        dt_c = time.perf_counter() - t0
+        value_cold = int(r.stats().ray_bounces) / dt_c / 1e6
+        next_iter += args.steps
     # clock settle (untimed, reported): the W warm-up steps last W x ~0.2 ms here, and the GPU needs ~50-100 ms of load
-    # to reach the clock it then holds (measured: --steps 20 after --warmup 5: 29.5 G, after --warmup 256: 35.1 G
-    # ray-bounces/s).  The same iterations of the same frame keep being rendered until the device has been busy for
+    # to reach the clock it then holds.  The same frame keeps being rendered until the device has been busy for
     # settle_ms; the timed region is untouched: exactly K steps, bracketed as before.
     settle_iters = 0
     chunk = 64
     while args.settle_ms > 0 and (time.perf_counter() - t_w) * 1e3 < args.settle_ms and settle_iters < 65536:
-        r.render(args.warmup + settle_iters + 1, chunk)
+        r.render(next_iter + settle_iters, chunk)
         r.synchronize()
         settle_iters += chunk
     if world > 1:
@@ -249,80 +277,134 @@ def main():
         dist.all_reduce(tmp, op=dist.ReduceOp.MAX)
         more = int(tmp[0]) - settle_iters
         if more > 0:
-            r.render(args.warmup + settle_iters + 1, more)
+            r.render(next_iter + settle_iters, more)
             settle_iters += more
     sync()
     r.reset_stats()
 
-    # timed region: exactly K steps + the one framebuffer gather for N>1.  The gather is the PREVIOUS frame's: a renderer
-    # in steady state (an animation, main.cpp's frame loop) hands frame f's tiles to RCCL while frame f+1 renders, so the
-    # exchange step runs on RCCL's stream beside the render stream instead of after it.  The snapshot stands for that
-    # finished frame (same bytes per rank); it is taken before the clock starts, the gather itself is inside.
-    first = args.warmup + settle_iters + 1
-    prev_frame_tile = fb.clone() if world > 1 else None
+    # timed region: exactly K steps, then (N > 1) the ONE framebuffer gather of the frame those steps rendered -- the
+    # path's only exchange step, dependent on the render, inside the barriers.
+    first = next_iter + settle_iters
     sync()
     t0 = time.perf_counter()
-    if world > 1:
-        frame = gather(prev_frame_tile)      # enqueued first: RCCL's stream (host-blocking only under the gloo rehearsal)
     r.render(first, args.steps)
     r.synchronize()
+    if world > 1:
+        frame = gather(fb)
     sync()
     dt = time.perf_counter() - t0
 
     st = r.stats()
     rb_local = int(st.ray_bounces)
     live_in = [int(x) for x in st.live_in[:args.depth]]
-    tens = torch.tensor([dt, float(rb_local), float(st.gpu_ms)], dtype=torch.float64, device="cpu" if rehearsal else dev)
+    reduce_dev = "cpu" if rehearsal else dev
+    tens = torch.tensor([dt, float(rb_local), float(st.gpu_ms)], dtype=torch.float64, device=reduce_dev)
+    gather_check = None
     if world > 1:
         tmax = tens.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tens.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt_max, rb_total = float(tmax[0]), float(tsum[1])
+        # the gathered frame against the ranks' own tiles: integer checksum of every tile's bit patterns
+        own = torch.tensor([tile_checksum(fb[:Hband])], dtype=torch.int64, device=reduce_dev)
+        sums = [torch.zeros_like(own) for _ in range(world)]
+        dist.all_gather(sums, own)
+        if rank == 0:
+            ok = True
+            for k in range(world):
+                if strips:
+                    rows = torch.as_tensor(sharding.strip_global_rows(Hfull, world, k), dtype=torch.long, device=frame.device)
+                    part = frame.index_select(0, rows)
+                else:
+                    k0, k1 = sharding.band_rows(Hfull, world, k)
+                    part = frame[k0:k1]
+                ok = ok and tile_checksum(part) == int(sums[k].item())
+            gather_check = "frame == rank tiles (integer checksum per rank)" if ok else "MISMATCH"
+            if not ok:
+                print("bench.py: the gathered frame does not match the ranks' tiles", file=sys.stderr, flush=True)
+        # second region (reported as value_pipelined_gather, never as `value`): a renderer in steady state hands frame f's
+        # tiles to RCCL while frame f + 1 renders -- the gather of a snapshot of the finished frame runs on RCCL's stream
+        # beside the next K steps
+        r.reset_stats()
+        prev_frame_tile = fb.clone()
+        sync()
+        t0p = time.perf_counter()
+        frame2 = gather(prev_frame_tile)     # enqueued first (host-blocking only under the gloo rehearsal)
+        r.render(first + args.steps, args.steps)
+        r.synchronize()
+        sync()
+        dtp = time.perf_counter() - t0p
+        st2 = r.stats()
+        tp = torch.tensor([dtp], dtype=torch.float64, device=reduce_dev)
+        dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        rp = torch.tensor([float(st2.ray_bounces)], dtype=torch.float64, device=reduce_dev)
+        dist.all_reduce(rp, op=dist.ReduceOp.SUM)
+        value_pipelined = float(rp[0]) / float(tp[0]) / 1e6
+        del frame2
+        next_free = first + 2 * args.steps
     else:
         dt_max, rb_total = dt, float(rb_local)
+        value_pipelined = None
+        next_free = first + args.steps
 
     if rank == 0:
         npix = W * Hband
         alg_bytes = pkg.algorithmic_bytes(npix, live_in, args.steps)      # this rank, the timed K steps
-        # dominant kernel: k_bounce, one HIP event pair per launch on the render stream (a few extra steps)
+        # Dominant kernel k_bounce.  Two launch sequences are in flight (batch n + 1 on a second stream beside batch n), so
+        # the kernel is priced over the TIMED REGION: its launches' algorithmic bytes / the HIP-event time of the region on
+        # the render stream (the library's own event pair around the pt_render call; it spans both sequences and includes
+        # the batches' accumulate and bookkeeping kernels, ~4 %: conservative).  A launch's own duration overlaps its
+        # neighbour's; `kernel_alone` below is the per-launch figure with one sequence (eager launches, one event pair each).
         lib_batch = args.batch or 16
         nb_timed = (args.steps + lib_batch - 1) // lib_batch
         timed_batches = [args.steps // nb_timed + (1 if j < args.steps % nb_timed else 0) for j in range(nb_timed)]
+        launches_timed = nb_timed * args.depth       # one launch carries one bounce of one batch
+        region_ms = float(st.gpu_ms)
+        achieved = alg_bytes / (region_ms * 1e-3) / 1e9
         prof_steps = timed_batches[0]          # one batch of the timed region's size: the same launch shape
         r.reset_stats()
-        bounce_ms = r.render_profiled(first + args.steps, prof_steps)
+        bounce_ms = r.render_profiled(next_free, prof_steps)
         pst = r.stats()
         p_live = [int(x) for x in pst.live_in[:args.depth]]
         p_bytes = pkg.algorithmic_bytes(npix, p_live, prof_steps)
         p_ms = sum(bounce_ms)
-        launches = int(pst.bounce_launches)      # one launch carries `batch` iterations of one bounce
-        achieved = p_bytes / (p_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC counters cannot be collected inside this run (rocprofv3 --pmc, one pass per
-        # counter group): the figure is the STORED result of the last collection for this config (profiles/collect_pmc.py)
-        traffic, traffic_source = None, None
+        p_launches = int(pst.bounce_launches)
+        # HBM bytes from the PMC counters cannot be collected inside this run (rocprofv3 --pmc, one pass per counter
+        # group): the figure is the STORED result of the last collection for this config (profiles/collect_pmc.py), kept
+        # per iteration-bounce and scaled to the iterations one launch of THIS run carries
+        traffic, traffic_source, flops_exec = None, None, None
+        iters_per_launch = args.steps / nb_timed
         if os.path.exists(args.traffic_json) and not args.custom and world == 1:
             try:
                 with open(args.traffic_json) as f:
                     ent = json.load(f).get(f"config{args.config}")
                 if ent:
-                    traffic, traffic_source = ent.get("hbm_bytes_per_launch"), "stored: " + str(ent.get("source"))
+                    traffic = ent["hbm_bytes_per_launch"] / ent.get("iterations_per_launch", 16) * iters_per_launch
+                    traffic_source = "stored: " + str(ent.get("source"))
+                    flops_exec = ent.get("executed_fp32_flops_per_ray_bounce")
             except Exception:
                 traffic = None
         tile_note = ", interleaved 8-row strips" if strips else ""
+        value = rb_total / dt_max / 1e6
         out = {
             "metric": "ray-bounces/sec",
-            "value": rb_total / dt_max / 1e6,
+            "value": value,
             "unit": "Mray-bounces/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "warmup_settle": {"extra_untimed_iterations": settle_iters, "settle_ms": args.settle_ms,
-                              "why": "GPU clock ramp (DVFS); the timed region is exactly `steps` iterations"},
+            "warmup_settle": {"extra_untimed_iterations": settle_iters + (args.steps if value_cold is not None else 0),
+                              "settle_ms": args.settle_ms,
+                              "why": "GPU clock ramp (DVFS); the timed region is exactly `steps` iterations; value_cold = the same "
+                                     "K steps right behind the W warm-up steps"},
+            "value_cold": value_cold,
             "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
+            "vs_baseline_note": "BASELINE.json `published` is empty (the reference renders noise and quotes no number); "
+                                "vs_cpu_baseline = value / cpu_baseline.value",
             "dtype": "f32",
             "data": "synthetic",
             "config": {
@@ -331,16 +413,20 @@ def main():
                             f"{args.depth} bounces, {CONFIGS[args.config]['lobes']}, rotat={args.rotat}, rr_start={args.rr_start}",
                 "baseline_config": args.config, "scene": args.scene, "width": W, "height": Hfull, "depth": args.depth, "spp": args.steps,
                 "rotat_units": args.rotat, "primitives": sc.n_objects, "materials": sc.n_materials,
-                "compaction": 0 if args.no_compaction else args.compaction, "iteration_batch": lib_batch, "timed_batches": timed_batches, "hip_graph": not args.no_graph, "direct_light": bool(args.direct_light),
-                "parallelism": (f"pixel-strips x{world}" if strips else f"pixel-bands x{world}") + (", 1 RCCL gather of the previous frame overlapped with the timed steps" if world > 1 else ""),
+                "compaction": 0 if args.no_compaction else args.compaction, "iteration_batch": lib_batch, "timed_batches": timed_batches,
+                "launch_sequences_in_flight": args.sequences or int(os.environ.get("PT_SEQUENCES", "2")),
+                "hip_graph": not args.no_graph, "direct_light": bool(args.direct_light),
+                "parallelism": (f"pixel-strips x{world}" if strips else f"pixel-bands x{world}") +
+                               (", 1 RCCL gather of the rendered frame behind the timed steps" if world > 1 else ""),
                 "gather_ms_standalone": gather_ms,
+                "gather_check": gather_check,
             },
             "ray_bounces": int(rb_total),
             "shadow_rays": int(st.shadow_rays),
             "live_in_per_bounce": live_in,
             "ms_per_frame_1spp": dt_max / args.steps * 1e3,
             "total_ms": dt_max * 1e3,
-            "gpu_event_ms": float(st.gpu_ms),
+            "gpu_event_ms": region_ms,
             "algorithmic_bytes_timed_region": alg_bytes,
             "algorithmic_GBs_whole_job": alg_bytes / dt_max / 1e9,
             "roofline": {
@@ -352,25 +438,44 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
-                "bytes_per_launch": p_bytes / launches,
-                "avg_launch_ms": p_ms / launches,
-                "launches_measured": launches,
-                "bytes_per_ray_bounce": p_bytes / max(1, sum(p_live)),
-                "note": "achieved = algorithmic bytes (SURVEY 8(d): P*40 + sum_b(live_in+live_out)*40 + P*24 per "
-                        "iteration) / summed k_bounce launch time from per-launch HIP events; the path is "
-                        "VALU/latency-bound, see DESIGN.md",
+                "bytes_per_launch": alg_bytes / launches_timed,
+                "avg_launch_ms": region_ms / launches_timed,
+                "launches_measured": launches_timed,
+                "iterations_per_launch": iters_per_launch,
+                "bytes_per_ray_bounce": alg_bytes / max(1, sum(live_in)),
+                "kernel_alone": {"avg_launch_ms": p_ms / p_launches, "bytes_per_launch": p_bytes / p_launches,
+                                 "achieved": p_bytes / (p_ms * 1e-3) / 1e9, "frac": p_bytes / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "launches_measured": p_launches,
+                                 "how": "one sequence, eager launches, one HIP event pair per launch (pt_render_profiled)"},
+                "note": "achieved = algorithmic bytes of the timed region's k_bounce launches (SURVEY 8(d): P*40 + "
+                        "sum_b(live_in+live_out)*40 + P*24 per iteration) / HIP-event time of the timed region on the render "
+                        "stream; avg_launch_ms = that time / launches: two launch sequences overlap, so a launch's own "
+                        "duration in a rocprofv3 kernel trace is longer than this -- profiles/trace_union.py turns a trace "
+                        "into the same figure (union of the k_bounce intervals / launches).  The path is VALU-issue-bound, "
+                        "see DESIGN.md 5.3",
             },
         }
-        # the physically binding roof is fp32 VALU issue; flops per ray-bounce = 95*nG + 150
-        # (nominal count of the intersection + shading arithmetic), peak = 157.3 TFLOP/s (FMA counted as 2 flops).
-        # The path's arithmetic is mul/add without contraction (bit parity), so at most half of that peak is
-        # reachable by construction.
+        if value_pipelined is not None:
+            out["value_pipelined_gather"] = value_pipelined
+            out["value_pipelined_gather_note"] = ("second region: the previous frame's tiles gathered on RCCL's stream while the "
+                                                  "next K steps render (steady state of an animation); `value` has the gather of "
+                                                  "the rendered frame behind the K steps")
+        # the physically binding roof is fp32 VALU issue.  nominal = 95*nG + 150 flops per ray-bounce (the
+        # survey's count of a test-everything renderer); executed = fp32 add/mul/fma instructions x active lanes (FMA = 2)
+        # from the stored PMC pass of this config, per ray-bounce.  Peak 157.3 TFLOP/s counts FMA as 2 flops; the path's
+        # arithmetic is mul/add without contraction (bit parity), so at most half of it is reachable by construction.
         flops_rb = 95 * sc.n_objects + 150
-        valu_tflops = sum(p_live) * flops_rb / (p_ms * 1e-3) / 1e12
-        out["valu_roofline"] = {"bound": "valu_fp32", "achieved": valu_tflops, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": valu_tflops / VALU_PEAK_TFLOPS, "flops_per_ray_bounce": flops_rb}
+        rate = sum(live_in) / (region_ms * 1e-3)
+        out["valu_roofline"] = {"bound": "valu_fp32", "achieved": rate * flops_rb / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": rate * flops_rb / 1e12 / VALU_PEAK_TFLOPS, "flops_per_ray_bounce": flops_rb,
+                                "kind": "nominal (95*nG + 150 per ray-bounce)",
+                                "executed": None if flops_exec is None else
+                                {"achieved": rate * flops_exec / 1e12, "frac": rate * flops_exec / 1e12 / VALU_PEAK_TFLOPS,
+                                 "flops_per_ray_bounce": flops_exec,
+                                 "how": "stored PMC pass: (SQ_INSTS_VALU_ADD_F32 + MUL_F32 + 2*FMA_F32) x average active lanes"}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, scene_path, rotat)
+            out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
 
     r.close()

@@ -29,6 +29,7 @@ extern "C" {
 
 #define PT_ABI_VERSION 1
 #define PT_MAX_DEPTH 64
+#define PT_MAX_SEQUENCES 4   /* launch sequences in flight per context (pt_options.sequences) */
 
 typedef enum pt_status {
     PT_OK = 0,
@@ -115,6 +116,10 @@ typedef struct pt_options {
                              a dielectric when REFR is set, index-matched otherwise; 0 = off (default) */
     float lens_radius;    /* > 0: thin-lens camera (depth of field): rays start on a disc of this radius around the eye and */
     float focal_distance; /*   aim at the pinhole ray's point on the plane focal_distance along the view axis; 0 = pinhole */
+    int sequences;        /* launch sequences in flight, 1..PT_MAX_SEQUENCES (default 0 = library choice): batch n + 1 of a
+                             pt_render call renders on a second stream, with ray pools of its own, while batch n does -- its
+                             launches fill the compute units the tail of every bounce launch leaves idle; only the accumulates
+                             are ordered (iteration order), so the image does not depend on it */
 } pt_options;
 
 typedef struct pt_stats {

@@ -103,6 +103,13 @@ def main():
                         summary["bench_under_trace"] = {k: j[k] for k in ("value", "steps", "warmup", "ms_per_step", "roofline")}
                     except Exception:
                         pass
+            # two launch sequences overlap: union of the k_bounce intervals (profiles/trace_union.py)
+            for fn in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+                u = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "trace_union.py"), fn], capture_output=True, text=True)
+                try:
+                    summary["k_bounce_trace_union"] = json.loads(u.stdout.strip().splitlines()[-1])
+                except Exception:
+                    pass
             for fn in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
                 with open(fn) as f:
                     for row in csv.DictReader(f):
@@ -114,6 +121,14 @@ def main():
                             k["total_ms"] = float(row["TotalDurationNs"]) / 1e6
                             k["pct"] = float(row["Percentage"])
         else:
+            for line in res.stdout.splitlines():             # the bench line of the pass (ray-bounces per iteration)
+                if line.startswith("{") and "bench_under_pmc" not in summary:
+                    try:
+                        j = json.loads(line)
+                        summary["bench_under_pmc"] = {"ray_bounces": j["ray_bounces"], "steps": j["steps"],
+                                                      "iteration_batch": j["config"]["iteration_batch"]}
+                    except Exception:
+                        pass
             for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(fn) as f:
                     for row in csv.DictReader(f):
@@ -161,9 +176,29 @@ def main():
     if kb.get("calls") and kf.get("calls"):
         der["trace_avg_launch_ms"] = (kb["total_ms"] + kf["total_ms"]) / (kb["calls"] + kf["calls"])
         der["trace_launches"] = kb["calls"] + kf["calls"]
+    # executed fp32 work per ray-bounce: (add + mul + 2 fma instructions) x that kernel instance's average active lanes over
+    # every k_bounce dispatch of the pass, over the ray-bounces those dispatches carried (every batch of a PMC pass is a
+    # full one: steps and warm-up are multiples of the batch)
+    bu = summary.get("bench_under_pmc")
+    if bu:
+        flops, nfirst = 0.0, 0
+        for kn in ("k_bounce", "k_bounce<first>"):
+            pm = summary["kernels"].get(kn, {}).get("pmc", {})
+            if not all(c in pm for c in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32",
+                                         "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU")):
+                flops = None
+                break
+            lanes = pm["SQ_THREAD_CYCLES_VALU"]["sum"] / pm["SQ_ACTIVE_INST_VALU"]["sum"]
+            flops += (pm["SQ_INSTS_VALU_ADD_F32"]["sum"] + pm["SQ_INSTS_VALU_MUL_F32"]["sum"] + 2.0 * pm["SQ_INSTS_VALU_FMA_F32"]["sum"]) * lanes
+            if kn.endswith(">"):
+                nfirst = pm["SQ_INSTS_VALU_FMA_F32"]["dispatches"]
+        if flops and nfirst:
+            der["executed_fp32_flops_per_ray_bounce"] = flops / (nfirst * bu["iteration_batch"] * bu["ray_bounces"] / bu["steps"])
     summary["k_bounce_derived"] = der
     if "hbm_bytes_per_launch" in der:
-        summary["traffic_for_bench"] = {"hbm_bytes_per_launch": der["hbm_bytes_per_launch"], "source": f"pmc_{a.tag}"}
+        summary["traffic_for_bench"] = {"hbm_bytes_per_launch": der["hbm_bytes_per_launch"], "iterations_per_launch": (bu or {}).get("iteration_batch", 16),
+                                        "executed_fp32_flops_per_ray_bounce": der.get("executed_fp32_flops_per_ray_bounce"),
+                                        "source": f"pmc_{a.tag}"}
     with open(os.path.join(out, "summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
     print(json.dumps(summary.get("k_bounce_derived"), indent=1))

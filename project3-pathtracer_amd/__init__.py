@@ -65,7 +65,8 @@ class Options(C.Structure):
     _fields_ = [("depth", C.c_int), ("rr_start", C.c_int), ("seed", C.c_uint), ("compaction", C.c_int),
                 ("workgroup", C.c_int), ("geom_path", C.c_int), ("row_begin", C.c_int), ("row_end", C.c_int),
                 ("use_graph", C.c_int), ("batch", C.c_int), ("direct_light", C.c_int), ("absorption", C.c_int), ("strip_rows", C.c_int), ("strip_world", C.c_int),
-                ("strip_rank", C.c_int), ("scatter", C.c_int), ("lens_radius", C.c_float), ("focal_distance", C.c_float)]
+                ("strip_rank", C.c_int), ("scatter", C.c_int), ("lens_radius", C.c_float), ("focal_distance", C.c_float),
+                ("sequences", C.c_int)]
 
 
 class Stats(C.Structure):

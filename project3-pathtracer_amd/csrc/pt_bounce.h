@@ -1,6 +1,6 @@
 // pt_bounce.h -- the per-bounce kernel k_bounce<WG, FIRST, GEOM, COMPACT, FEAT> and the nearest-hit machinery behind it
 // (raycastFromCameraKernel fused into bounce 0, one bounce of raytraceRay, stream compaction: see pt_kernels.hip's header).
-// Templates only: each geometry path is instantiated in its own translation unit (pt_bounce_g<N>.hip) so that the seven
+// Templates only: each geometry path is instantiated in its own translation unit (pt_bounce_g<N>.hip) so that the eight
 // of them compile in parallel; pt_kernels.hip picks the instance at launch time through bounce_kernel_g<N>().
 #pragma once
 #include <stdlib.h>

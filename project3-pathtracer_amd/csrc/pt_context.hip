@@ -79,7 +79,12 @@ struct pt_ctx {
 
     // device state
     bool dirty = true;          // scene / camera / options changed since the last configure
-    pt::KParams kp;
+    pt::KParams kp;             // sequence 0's parameters (what everything outside the launch sequencing reads)
+    pt::KParams kps[PT_MAX_SEQUENCES];   // per launch sequence: own ray pools, radiance planes and IterState
+    int nseq = 1;               // launch sequences in flight (pt_options.sequences)
+    hipStream_t seq_stream[PT_MAX_SEQUENCES] = {};   // [0] = `stream`; [k > 0] own streams
+    hipEvent_t seq_acc[PT_MAX_SEQUENCES] = {};       // recorded behind a sequence's accumulate
+    hipEvent_t seq_fork = nullptr;
     pt::LaunchCfg cfg;
     ptd::Prim *d_prims = nullptr;
     float *d_mats = nullptr;
@@ -105,11 +110,14 @@ struct pt_ctx {
     float *d_lbuf = nullptr;    // per-iteration radiance planes of the running batch
     size_t lbuf_cap = 0;
     int batch = 1;              // iterations in flight per launch sequence
-    pt::IterState *d_state = nullptr;
+    pt::IterState *d_state = nullptr;          // PT_MAX_SEQUENCES of them
     bool image_valid = false;   // framebuffer holds iterations 1..k of the current frame
 
-    hipGraph_t graph = nullptr;          // one batch (bookkeeping, depth bounce launches, accumulate); the batch's
-    hipGraphExec_t graph_exec = nullptr; //   iteration count lives on the device, so this graph serves every pt_render
+    // one batch of one sequence (bookkeeping, depth bounce launches; with a single sequence also the accumulate); the
+    // batch's iteration count lives on the device, so this graph serves every pt_render
+    // slots [0, PT_MAX_SEQUENCES): a sequence's batch without the accumulate; slot PT_MAX_SEQUENCES: sequence 0's with it
+    hipGraph_t graph[PT_MAX_SEQUENCES + 1] = {};
+    hipGraphExec_t graph_exec[PT_MAX_SEQUENCES + 1] = {};
 
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timers;
     double gpu_ms = 0.0;
@@ -120,8 +128,10 @@ namespace {
 
 void drop_graph(pt_ctx *c)
 {
-    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
-    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+    for (int q = 0; q <= PT_MAX_SEQUENCES; ++q) {
+        if (c->graph_exec[q]) { (void)hipGraphExecDestroy(c->graph_exec[q]); c->graph_exec[q] = nullptr; }
+        if (c->graph[q]) { (void)hipGraphDestroy(c->graph[q]); c->graph[q] = nullptr; }
+    }
 }
 
 int fold_timers(pt_ctx *c)
@@ -194,30 +204,81 @@ void build_bvh(const std::vector<Aabb> &boxes, std::vector<int> &idx, size_t lo,
             }
         };
         double best_cost = 1e300;
-        int best_axis = 0;
+        int best_axis = -1;
         size_t best_left = n / 2;
-        std::vector<int> order(n), best_order;
-        std::vector<double> right_area(n);
-        for (int axis = 0; axis < 3; ++axis) {
-            if (!(cmax[axis] > cmin[axis])) continue;
-            std::copy(idx.begin() + (long)lo, idx.begin() + (long)hi, order.begin());
-            std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+        auto by_centroid = [&](int axis) {
+            return [&boxes, axis](int x, int y) {
                 return boxes[(size_t)x].lo[axis] + boxes[(size_t)x].hi[axis] < boxes[(size_t)y].lo[axis] + boxes[(size_t)y].hi[axis];
-            });
-            Aabb acc = boxes[(size_t)order[n - 1]];
-            for (size_t k = n - 1; k >= 1; --k) {                 // right_area[k] = area of order[k..n)
-                grow(acc, boxes[(size_t)order[k]]);
-                right_area[k] = half_area(acc);
+            };
+        };
+        if (n <= 4096) {
+            // full sweep; only (axis, split position) of the best split are kept during it -- the winning order is rebuilt
+            // by one more sort afterwards (stable_sort of the same input: the same order)
+            std::vector<int> order(n);
+            std::vector<double> right_area(n);
+            for (int axis = 0; axis < 3; ++axis) {
+                if (!(cmax[axis] > cmin[axis])) continue;
+                std::copy(idx.begin() + (long)lo, idx.begin() + (long)hi, order.begin());
+                std::stable_sort(order.begin(), order.end(), by_centroid(axis));
+                Aabb acc = boxes[(size_t)order[n - 1]];
+                for (size_t k = n - 1; k >= 1; --k) {                 // right_area[k] = area of order[k..n)
+                    grow(acc, boxes[(size_t)order[k]]);
+                    right_area[k] = half_area(acc);
+                }
+                acc = boxes[(size_t)order[0]];
+                for (size_t k = 1; k < n; ++k) {                      // split: left = order[0..k), right = order[k..n)
+                    grow(acc, boxes[(size_t)order[k - 1]]);
+                    const double cost = half_area(acc) * (double)k + right_area[k] * (double)(n - k);
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_left = k; }
+                }
             }
-            acc = boxes[(size_t)order[0]];
-            for (size_t k = 1; k < n; ++k) {                      // split: left = order[0..k), right = order[k..n)
-                grow(acc, boxes[(size_t)order[k - 1]]);
-                const double cost = half_area(acc) * (double)k + right_area[k] * (double)(n - k);
-                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_left = k; best_order = order; }
+            if (best_axis >= 0) std::stable_sort(idx.begin() + (long)lo, idx.begin() + (long)hi, by_centroid(best_axis));
+        } else {
+            // large nodes (triangle meshes): binned surface-area heuristic, 32 centroid bins per axis, O(n) per node
+            constexpr int NB = 32;
+            int best_bin = -1;
+            for (int axis = 0; axis < 3; ++axis) {
+                if (!(cmax[axis] > cmin[axis])) continue;
+                Aabb bb[NB];
+                size_t cnt[NB] = {0};
+                const double scale = (double)NB / ((double)cmax[axis] - (double)cmin[axis]);
+                auto bin_of = [&](int x) {
+                    const double cc = 0.5 * ((double)boxes[(size_t)x].lo[axis] + (double)boxes[(size_t)x].hi[axis]);
+                    int b = (int)((cc - (double)cmin[axis]) * scale);
+                    return b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                };
+                for (size_t k = lo; k < hi; ++k) {
+                    const int b = bin_of(idx[k]);
+                    if (cnt[b]++ == 0) bb[b] = boxes[(size_t)idx[k]]; else grow(bb[b], boxes[(size_t)idx[k]]);
+                }
+                double ra[NB];
+                size_t rc[NB];
+                Aabb acc{};
+                size_t c2 = 0;
+                for (int b = NB - 1; b >= 1; --b) {                  // right side = bins [b, NB)
+                    if (cnt[b]) { if (c2 == 0) acc = bb[b]; else grow(acc, bb[b]); c2 += cnt[b]; }
+                    ra[b] = c2 ? half_area(acc) : 0.0;
+                    rc[b] = c2;
+                }
+                c2 = 0;
+                for (int b = 1; b < NB; ++b) {                       // left side = bins [0, b)
+                    if (cnt[b - 1]) { if (c2 == 0) acc = bb[b - 1]; else grow(acc, bb[b - 1]); c2 += cnt[b - 1]; }
+                    if (c2 == 0 || rc[b] == 0) continue;
+                    const double cost = half_area(acc) * (double)c2 + ra[b] * (double)rc[b];
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; best_left = c2; }
+                }
+            }
+            if (best_axis >= 0) {
+                const int axis = best_axis;
+                const double scale = (double)NB / ((double)cmax[axis] - (double)cmin[axis]);
+                std::stable_partition(idx.begin() + (long)lo, idx.begin() + (long)hi, [&](int x) {
+                    const double cc = 0.5 * ((double)boxes[(size_t)x].lo[axis] + (double)boxes[(size_t)x].hi[axis]);
+                    int b = (int)((cc - (double)cmin[axis]) * scale);
+                    b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                    return b < best_bin;
+                });
             }
         }
-        (void)best_axis;
-        if (!best_order.empty()) std::copy(best_order.begin(), best_order.end(), idx.begin() + (long)lo);
         const size_t mid = lo + best_left;
         nodes[me].prim = -1;
         build_bvh(boxes, idx, lo, mid, nodes);
@@ -687,7 +748,19 @@ int configure(pt_ctx *c)
         if (o.geom_path == 0) cfg.geom = 6;
         else if (!(cfg.geom == 0 || cfg.geom == 6 || cfg.geom == 7))
             return fail(PT_ERR_INVALID, "scenes with triangle meshes need geom_path 0, 1, 7 or 8 (got %d)", o.geom_path);
-        if (k.nG >= (1 << 20)) return fail(PT_ERR_INVALID, "%d primitives (triangles included): at most %d", k.nG, (1 << 20) - 1);
+    }
+    // the batched walks and the pair queues keep 20-bit primitive / node indices beside their flag bits
+    if ((cfg.geom == 4 || cfg.geom == 5 || cfg.geom == 6 || cfg.geom == 7) && (k.nG >= (1 << 20) || k.nnodes4 >= (1 << 20))) {
+        if (o.geom_path != 0)
+            return fail(PT_ERR_INVALID, "%d primitives (triangles included), %d wide nodes: at most %d on this geometry path", k.nG, k.nnodes4, (1 << 20) - 1);
+        cfg.geom = 0;
+    }
+    // the batched walk's entry ring must hold a full batch above its depth-first reserve (pt_bounce.h W4_STACK = 512): a
+    // degenerate hierarchy (e.g. sizes in a long geometric progression) can be deeper than that allows
+    if ((cfg.geom == 6 || cfg.geom == 7) && 64 + 3 * k.wdepth + 4 > 512) {
+        if (o.geom_path != 0)
+            return fail(PT_ERR_INVALID, "hierarchy depth %d: the batched walk's entry ring holds at most depth %d", k.wdepth, (512 - 64 - 4) / 3);
+        cfg.geom = 0;
     }
     cfg.compact = o.compaction;
     cfg.nee = k.nlights > 0 ? 1 : 0;             // no lights: nothing to sample, the plain kernels are exact
@@ -761,13 +834,23 @@ int configure(pt_ctx *c)
         fprintf(stderr, "[ptamd] launch: geom %d, workgroup %d, %zu B LDS, %d workgroups/CU, grid %d, batch %d\n", cfg.geom, cfg.workgroup,
                 lds, per_cu, cfg.grid, batch);
 
-    // per-iteration radiance planes (one write per path, folded into the image by k_accumulate)
-    const size_t lbuf_bytes = (size_t)nrays * 3 * sizeof(float);
-    if (c->lbuf_cap < lbuf_bytes) {
+    // Launch sequences in flight: sequence q renders batches q, q + nseq, ... of a pt_render call on a stream of its own,
+    // with its own ray pools, radiance planes and IterState; only the accumulates are ordered across the sequences
+    // (iteration order).  The workgroups of a bounce launch do not finish together -- their lifetimes spread over
+    // 65..100 % of the launch -- and a second sequence's launches fill the compute units the first one's tail leaves idle.
+    // Library choice: two (config 2 on one box: 37.2 / 43.0 / 42.9 / 41.4 G ray-bounces/s with 1 / 2 / 3 / 4 sequences;
+    // config 5: 17.7 / 20.5 / 19.7 / 18.8 G -- profiles/r03/sweep_sequences.txt).
+    int nseq = o.sequences == 0 ? 2 : o.sequences;
+    if (getenv("PT_SEQUENCES") && atoi(getenv("PT_SEQUENCES")) >= 1 && atoi(getenv("PT_SEQUENCES")) <= PT_MAX_SEQUENCES)
+        nseq = atoi(getenv("PT_SEQUENCES"));
+    c->nseq = nseq;
+    // per-iteration radiance planes (one write per path, folded into the image by k_accumulate), per sequence
+    const size_t lbuf_bytes = ((size_t)nrays * 3 * sizeof(float) + 255) & ~(size_t)255;
+    if (c->lbuf_cap < lbuf_bytes * (size_t)nseq) {
         if (c->d_lbuf) (void)hipFree(c->d_lbuf);
         c->d_lbuf = nullptr; c->lbuf_cap = 0;
-        HIP_TRY(hipMalloc((void **)&c->d_lbuf, lbuf_bytes));
-        c->lbuf_cap = lbuf_bytes;
+        HIP_TRY(hipMalloc((void **)&c->d_lbuf, lbuf_bytes * (size_t)nseq));
+        c->lbuf_cap = lbuf_bytes * (size_t)nseq;
     }
     k.lbuf = c->d_lbuf;
 
@@ -951,18 +1034,31 @@ int configure(pt_ctx *c)
     }
     const size_t slots = (size_t)k.segcap * (size_t)k.nshard;
     const size_t one = slots * (16 + 16 + 8);
-    if (c->pool_cap < 2 * one) {
+    if (c->pool_cap < 2 * one * (size_t)nseq) {
         if (c->d_pool) (void)hipFree(c->d_pool);
         c->d_pool = nullptr; c->pool_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_pool, 2 * one));
-        c->pool_cap = 2 * one;
+        HIP_TRY(hipMalloc(&c->d_pool, 2 * one * (size_t)nseq));
+        c->pool_cap = 2 * one * (size_t)nseq;
     }
-    for (int q = 0; q < 2; ++q) {
-        unsigned char *base = (unsigned char *)c->d_pool + (size_t)q * one;
-        k.pool[q].a = (float4 *)base;
-        k.pool[q].b = (float4 *)(base + slots * 16);
-        k.pool[q].c = (float2 *)(base + slots * 32);
+    for (int sq = 0; sq < PT_MAX_SEQUENCES; ++sq) {
+        pt::KParams &ks = c->kps[sq];
+        ks = k;
+        if (sq >= nseq) continue;
+        for (int q = 0; q < 2; ++q) {
+            unsigned char *base = (unsigned char *)c->d_pool + (size_t)(2 * sq + q) * one;
+            ks.pool[q].a = (float4 *)base;
+            ks.pool[q].b = (float4 *)(base + slots * 16);
+            ks.pool[q].c = (float2 *)(base + slots * 32);
+        }
+        ks.lbuf = (float *)((unsigned char *)c->d_lbuf + (size_t)sq * lbuf_bytes);
+        ks.st = c->d_state + sq;
     }
+    k = c->kps[0];
+    if (getenv("PT_PRETOUCH")) {                     // experiment: write every pool / plane byte once before the first launch
+        HIP_TRY(hipMemsetAsync(c->d_pool, 0, 2 * one * (size_t)nseq, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_lbuf, 0, lbuf_bytes * (size_t)nseq, c->stream));
+    }
+    if (getenv("PT_DEBUG_CLOCK")) fprintf(stderr, "[ptamd] launch sequences in flight: %d\n", nseq);
 
     c->dirty = false;
     return PT_OK;
@@ -971,16 +1067,18 @@ int configure(pt_ctx *c)
 // one launch sequence = one batch of consecutive iterations (their number is device state, IterState::nslot):
 // bookkeeping, depth bounce launches, accumulate.
 // ev (optional): 2*depth events recorded around the bounce launches (pt_render_profiled).
-int enqueue_batch(pt_ctx *c, hipStream_t s, hipEvent_t *ev)
+// sq: the launch sequence (its pools, planes and IterState); with_accumulate = false leaves the accumulate to the caller,
+// who orders it behind the previous batch's.
+int enqueue_batch(pt_ctx *c, hipStream_t s, hipEvent_t *ev, int sq = 0, bool with_accumulate = true)
 {
-    const pt::KParams &kp = c->kp;
-    HIP_TRY(pt::launch_iter_begin(s, c->d_state, kp.npix, kp.depth, c->cfg.compact));
+    const pt::KParams &kp = c->kps[sq];
+    HIP_TRY(pt::launch_iter_begin(s, kp.st, kp.npix, kp.depth, c->cfg.compact));
     for (int b = 0; b < kp.depth; ++b) {
         if (ev) HIP_TRY(hipEventRecord(ev[2 * b], s));
         HIP_TRY(pt::launch_bounce(s, kp, c->cfg, b));
         if (ev) HIP_TRY(hipEventRecord(ev[2 * b + 1], s));
     }
-    HIP_TRY(pt::launch_accumulate(s, kp.image, kp.lbuf, c->d_state, kp.npix));
+    if (with_accumulate) HIP_TRY(pt::launch_accumulate(s, kp.image, kp.lbuf, kp.st, kp.npix));
     return PT_OK;
 }
 
@@ -1122,8 +1220,8 @@ int pt_create(int device, pt_ctx **out)
         return fail(PT_ERR_HIP, "hipStreamCreate failed");
     }
     c->stream = c->own_stream;
-    if (hipMalloc((void **)&c->d_state, sizeof(pt::IterState)) != hipSuccess ||
-        hipMemset(c->d_state, 0, sizeof(pt::IterState)) != hipSuccess) {
+    if (hipMalloc((void **)&c->d_state, PT_MAX_SEQUENCES * sizeof(pt::IterState)) != hipSuccess ||
+        hipMemset(c->d_state, 0, PT_MAX_SEQUENCES * sizeof(pt::IterState)) != hipSuccess) {
         pt_destroy(c);
         return fail(PT_ERR_OOM, "cannot allocate iteration state");
     }
@@ -1153,6 +1251,13 @@ void pt_destroy(pt_ctx *c)
     if (c->d_pool) (void)hipFree(c->d_pool);
     if (c->d_lbuf) (void)hipFree(c->d_lbuf);
     if (c->d_state) (void)hipFree(c->d_state);
+    if (c->d_span_off) (void)hipFree(c->d_span_off);
+    if (c->d_span_list) (void)hipFree(c->d_span_list);
+    for (int q = 1; q < PT_MAX_SEQUENCES; ++q)
+        if (c->seq_stream[q]) { (void)hipStreamSynchronize(c->seq_stream[q]); (void)hipStreamDestroy(c->seq_stream[q]); }
+    for (int q = 0; q < PT_MAX_SEQUENCES; ++q)
+        if (c->seq_acc[q]) (void)hipEventDestroy(c->seq_acc[q]);
+    if (c->seq_fork) (void)hipEventDestroy(c->seq_fork);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1177,6 +1282,7 @@ int pt_set_options(pt_ctx *c, const pt_options *o)
     if (o->scatter < 0 || o->scatter > 1) return fail(PT_ERR_INVALID, "scatter %d not 0 or 1", o->scatter);
     if (!(o->lens_radius >= 0.0f) || (o->lens_radius > 0.0f && !(o->focal_distance > 0.0f)))
         return fail(PT_ERR_INVALID, "lens radius %g / focal distance %g", (double)o->lens_radius, (double)o->focal_distance);
+    if (o->sequences < 0 || o->sequences > PT_MAX_SEQUENCES) return fail(PT_ERR_INVALID, "sequences %d not in 0..%d", o->sequences, PT_MAX_SEQUENCES);
     if (o->direct_light && o->compaction != 1) return fail(PT_ERR_INVALID, "direct_light needs compaction 1 (got %d)", o->compaction);
     if (o->scatter && o->compaction != 1) return fail(PT_ERR_INVALID, "scatter needs compaction 1 (got %d)", o->compaction);
     c->opt = *o;
@@ -1377,6 +1483,36 @@ int pt_render(pt_ctx *c, int iter_first, int iter_count)
         return PT_OK;
     }
 
+    int nb, q, r;
+    batch_schedule(iter_count, c->batch, &nb, &q, &r);
+    // sequences actually used by this call (a call of one batch runs on sequence 0 alone)
+    const int nseq = nb < c->nseq ? nb : c->nseq;
+    const bool own_acc = nseq > 1;       // the accumulates are ordered across the sequences by events, outside the graphs
+    c->seq_stream[0] = s;
+    if (c->nseq > 1) {
+        for (int sq = 1; sq < c->nseq; ++sq)
+            if (!c->seq_stream[sq]) HIP_TRY(hipStreamCreateWithFlags(&c->seq_stream[sq], hipStreamNonBlocking));
+        for (int sq = 0; sq < c->nseq; ++sq)
+            if (!c->seq_acc[sq]) HIP_TRY(hipEventCreateWithFlags(&c->seq_acc[sq], hipEventDisableTiming | hipEventDisableSystemFence));
+        if (!c->seq_fork) HIP_TRY(hipEventCreateWithFlags(&c->seq_fork, hipEventDisableTiming | hipEventDisableSystemFence));
+    }
+    if (c->opt.use_graph) {
+        // every graph this configuration can replay is captured by its first pt_render, whatever that call's size: slots
+        // [0, nseq) = a sequence's batch without the accumulate, slot PT_MAX_SEQUENCES = sequence 0's with it (one-batch
+        // calls) -- a later, longer call then meets no capture / instantiate (milliseconds of host time) on its way
+        for (int gs = 0; gs <= PT_MAX_SEQUENCES; ++gs) {
+            const bool whole = gs == PT_MAX_SEQUENCES;
+            if ((!whole && (c->nseq < 2 || gs >= c->nseq)) || c->graph_exec[gs]) continue;
+            const int sq = whole ? 0 : gs;
+            hipStream_t ss = c->seq_stream[sq];
+            HIP_TRY(hipStreamBeginCapture(ss, hipStreamCaptureModeThreadLocal));
+            rc = enqueue_batch(c, ss, nullptr, sq, whole);
+            hipError_t ce = hipStreamEndCapture(ss, &c->graph[gs]);
+            if (rc != PT_OK) { drop_graph(c); return rc; }
+            if (ce != hipSuccess) { drop_graph(c); return fail(PT_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce)); }
+            HIP_TRY(hipGraphInstantiate(&c->graph_exec[gs], c->graph[gs], nullptr, nullptr, 0));
+        }
+    }
     if (c->timers.size() >= 1024) { rc = fold_timers(c); if (rc != PT_OK) return rc; }
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreateWithFlags(&e0, hipEventDisableSystemFence));
@@ -1384,23 +1520,39 @@ int pt_render(pt_ctx *c, int iter_first, int iter_count)
     c->timers.emplace_back(e0, e1);
     HIP_TRY(hipEventRecord(e0, s));
 
-    int nb, q, r;
-    batch_schedule(iter_count, c->batch, &nb, &q, &r);
-    HIP_TRY(pt::launch_iter_set(s, c->d_state, (uint32_t)iter_first, (uint32_t)q, (uint32_t)r));
-    if (c->opt.use_graph) {
-        if (!c->graph_exec) {
-            HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            rc = enqueue_batch(c, s, nullptr);
-            hipError_t ce = hipStreamEndCapture(s, &c->graph);
-            if (rc != PT_OK) { drop_graph(c); return rc; }
-            if (ce != hipSuccess) { drop_graph(c); return fail(PT_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce)); }
-            HIP_TRY(hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
-        }
-        for (int i = 0; i < nb; ++i) HIP_TRY(hipGraphLaunch(c->graph_exec, s));
-    } else {
-        for (int i = 0; i < nb; ++i) { rc = enqueue_batch(c, s, nullptr); if (rc != PT_OK) return rc; }
+    if (nseq > 1) {
+        // fork: the other sequences start behind everything already on the render stream
+        HIP_TRY(hipEventRecord(c->seq_fork, s));
+        for (int sq = 1; sq < nseq; ++sq) HIP_TRY(hipStreamWaitEvent(c->seq_stream[sq], c->seq_fork, 0));
     }
-    HIP_TRY(pt::launch_iter_fold(s, c->d_state, c->kp.depth));
+    for (int sq = 0; sq < nseq; ++sq)
+        HIP_TRY(pt::launch_iter_set(c->seq_stream[sq], c->d_state + sq, (uint32_t)iter_first, (uint32_t)q, (uint32_t)r, (uint32_t)sq, (uint32_t)nseq));
+    for (int i = 0; i < nb; ++i) {
+        const int sq = i % nseq;
+        hipStream_t ss = c->seq_stream[sq];
+        if (c->opt.use_graph) {
+            const int gs = own_acc ? sq : PT_MAX_SEQUENCES;       // (a one-batch call runs on sequence 0 with its accumulate)
+            HIP_TRY(hipGraphLaunch(c->graph_exec[gs], ss));
+        } else {
+            rc = enqueue_batch(c, ss, nullptr, sq, !own_acc);
+            if (rc != PT_OK) return rc;
+        }
+        if (own_acc) {
+            // the running mean takes the batches in iteration order: batch i's accumulate behind batch i - 1's
+            if (i > 0) HIP_TRY(hipStreamWaitEvent(ss, c->seq_acc[(i - 1) % nseq], 0));
+            const pt::KParams &ks = c->kps[sq];
+            HIP_TRY(pt::launch_accumulate(ss, ks.image, ks.lbuf, ks.st, ks.npix));
+            HIP_TRY(hipEventRecord(c->seq_acc[sq], ss));
+        }
+    }
+    for (int sq = 0; sq < nseq; ++sq) HIP_TRY(pt::launch_iter_fold(c->seq_stream[sq], c->d_state + sq, c->kp.depth));
+    if (nseq > 1) {
+        // join: the render stream continues behind every sequence
+        for (int sq = 1; sq < nseq; ++sq) {
+            HIP_TRY(hipEventRecord(c->seq_acc[sq], c->seq_stream[sq]));
+            HIP_TRY(hipStreamWaitEvent(s, c->seq_acc[sq], 0));
+        }
+    }
     HIP_TRY(hipEventRecord(e1, s));
     c->bounce_launches += (unsigned long long)nb * (unsigned long long)c->kp.depth;
     c->image_valid = true;
@@ -1424,7 +1576,7 @@ int pt_render_profiled(pt_ctx *c, int iter_first, int iter_count, double *bounce
     for (auto &e : ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
     int nb, q, r;
     batch_schedule(iter_count, c->batch, &nb, &q, &r);
-    HIP_TRY(pt::launch_iter_set(s, c->d_state, (uint32_t)iter_first, (uint32_t)q, (uint32_t)r));
+    HIP_TRY(pt::launch_iter_set(s, c->d_state, (uint32_t)iter_first, (uint32_t)q, (uint32_t)r, 0u, 1u));
     int launches = 0;
     for (int i = 0; i < nb; ++i) {
         rc = enqueue_batch(c, s, ev.data());
@@ -1527,6 +1679,13 @@ int pt_get_stats(pt_ctx *c, pt_stats *out)
     memset(out, 0, sizeof *out);
     out->iterations = h.iterations;
     for (int b = 0; b < PT_MAX_DEPTH; ++b) { out->live_in[b] = h.live_in[b]; out->ray_bounces += h.live_in[b]; }
+    for (int sq = 1; sq < PT_MAX_SEQUENCES; ++sq) {         // the other launch sequences' counts (diagnostics: sequence 0's)
+        pt::IterState h2;
+        HIP_TRY(hipMemcpy(&h2, c->d_state + sq, sizeof h2, hipMemcpyDeviceToHost));
+        out->iterations += h2.iterations;
+        for (int b = 0; b < PT_MAX_DEPTH; ++b) { out->live_in[b] += h2.live_in[b]; out->ray_bounces += h2.live_in[b]; }
+        h.shadow_rays += h2.shadow_rays;
+    }
     out->gpu_ms = c->gpu_ms;
     if (getenv("PT_DEBUG_CLOCK")) fprintf(stderr, "[ptamd] cull: tested %llu skipped %llu (wave x primitive)\n", h.clk[2], h.clk[3]);
     if (getenv("PT_DEBUG_CLOCK") && h.clk[1])
@@ -1586,7 +1745,7 @@ int pt_reset_stats(pt_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     int rc = fold_timers(c);
     if (rc != PT_OK) return rc;
-    HIP_TRY(hipMemset(c->d_state, 0, sizeof(pt::IterState)));
+    HIP_TRY(hipMemset(c->d_state, 0, PT_MAX_SEQUENCES * sizeof(pt::IterState)));
     c->gpu_ms = 0.0;
     c->bounce_launches = 0;
     for (pt_ctx *ch : c->slice_ctx) { rc = pt_reset_stats(ch); if (rc != PT_OK) return rc; }

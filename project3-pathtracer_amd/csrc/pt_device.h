@@ -242,7 +242,7 @@ __device__ __forceinline__ f3 pointOnRay(f3 o, f3 d, float t) { return o + (t - 
 // ---------------------------------------------------------------------------------------------
 // RO_GIVEN: `ro` already holds inverseTransform*(origin,1) -- for camera rays it is the same for every lane and
 // is evaluated once per primitive on the host with the same operation order.
-// Triangle records (type 2, the flattened MESH geoms): inv[0..8] = v0, e1, e2 in WORLD space, fwd[0..2] = unit normal.
+// Triangle records (type 3, the flattened MESH geoms): inv[0..8] = v0, e1, e2 in WORLD space, fwd[0..2] = unit normal.
 // Moeller-Trumbore, two-sided, on the ray with its direction normalised first (as the sphere test does); ro = the ray
 // origin, t = distance along rd.  Same operations in the same order as the oracle's o_triangleIntersectionTest.
 __device__ __forceinline__ bool candidateTriangle(const float *w, f3 o, f3 d, f3 &ro, f3 &rd, float &t)
@@ -264,7 +264,7 @@ __device__ __forceinline__ bool candidateTriangle(const float *w, f3 o, f3 d, f3
     return t > 0.0f;
 }
 
-// TRI: the call site may meet triangle records (type 2); without it type 2 never hits (a MESH geom has no geometry of
+// TRI: the call site may meet triangle records (type 3); without it types 2 and 3 never hit (a MESH geom has no geometry of
 // its own: its triangles are primitives of their own behind the geoms)
 template <bool RO_GIVEN = false, bool TRI = false>
 __device__ __forceinline__ bool candidateT(uint32_t type, const float *inv, f3 o, f3 d, f3 &ro, f3 &rd, float &t,

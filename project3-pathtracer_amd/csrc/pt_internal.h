@@ -36,7 +36,10 @@ struct IterState {
     // iterations; k_iter_begin advances `iter` by the previous batch and sets `nslot` for the one that starts.
     uint32_t nslot;                              // iterations in flight in the running batch (1..PT_MAX_BATCH)
     uint32_t sched_q, sched_r, sched_j;          // batch size, batches that carry one more, index of the next batch
-    uint32_t pad[27];
+    // Launch sequences in flight (pt_options.sequences): every sequence has an IterState of its own and takes every
+    // sched_stride-th batch of the call, starting with its own number; a batch's first iteration follows from its index
+    uint32_t sched_first, sched_stride;          // first iteration of the pt_render call; batches between two of this sequence's
+    uint32_t pad[25];
     uint32_t counts[(PT_MAX_DEPTH + 1) * NSHARD * CNT_STRIDE];   // live rays entering bounce b, per segment
     unsigned long long live_in[PT_MAX_DEPTH];    // summed over segments and iterations (stats)
     unsigned long long iterations;
@@ -109,7 +112,7 @@ struct LaunchCfg {
 };
 
 // kernels (pt_kernels.hip)
-hipError_t launch_iter_set(hipStream_t s, IterState *st, uint32_t iter_first, uint32_t q, uint32_t r);
+hipError_t launch_iter_set(hipStream_t s, IterState *st, uint32_t iter_first, uint32_t q, uint32_t r, uint32_t j0, uint32_t stride);
 hipError_t launch_iter_begin(hipStream_t s, IterState *st, int npix, int depth, int compact);
 hipError_t launch_accumulate(hipStream_t s, float *image, const float *lbuf, const IterState *st, int npix);
 hipError_t launch_iter_fold(hipStream_t s, IterState *st, int depth);

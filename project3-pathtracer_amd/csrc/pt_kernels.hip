@@ -136,23 +136,27 @@ hipError_t launch_selftest_math(hipStream_t s, unsigned long long *out)
 // ---------------------------------------------------------------------------------------------
 // iteration bookkeeping
 // ---------------------------------------------------------------------------------------------
-// starts a pt_render call: first iteration and the batch schedule (q iterations per batch, the first r batches one more)
-__global__ void k_iter_set(IterState *st, uint32_t iter_first, uint32_t q, uint32_t r)
+// starts a pt_render call: first iteration and the batch schedule (q iterations per batch, the first r batches one more);
+// this launch sequence renders batches j0, j0 + stride, ... of the call
+__global__ void k_iter_set(IterState *st, uint32_t iter_first, uint32_t q, uint32_t r, uint32_t j0, uint32_t stride)
 {
     st->iter = iter_first;
     st->nslot = 0u;
     st->sched_q = q;
     st->sched_r = r;
-    st->sched_j = 0u;
+    st->sched_j = j0;
+    st->sched_first = iter_first;
+    st->sched_stride = stride;
 }
 
-// starts a batch: fold the previous batch's per-bounce live counts into the stats, reset them, advance the iteration
-// counter past the previous batch and publish this batch's iteration count (st->iter = first iteration of the batch)
+// starts a batch: fold the sequence's previous batch's per-bounce live counts into the stats, reset them, and publish this
+// batch's first iteration and iteration count (batch j of the call starts j*q + min(j, r) iterations after the call's first)
 __global__ void k_iter_begin(IterState *st, uint32_t npix, int depth, int compact)
 {
     const int b = threadIdx.x;
-    const uint32_t prev = st->nslot, j = st->sched_j;
+    const uint32_t j = st->sched_j;
     const uint32_t nslot = st->sched_q + (j < st->sched_r ? 1u : 0u);
+    const uint32_t iter = st->sched_first + j * st->sched_q + (j < st->sched_r ? j : st->sched_r);
     __syncthreads();                             // everyone has read the schedule before thread 0 moves it on
     if (b <= depth) {
         unsigned long long sum = 0;
@@ -163,9 +167,9 @@ __global__ void k_iter_begin(IterState *st, uint32_t npix, int depth, int compac
         if (b < depth) st->live_in[b] += sum;
     }
     if (b == 0) {
-        st->iter += prev;
+        st->iter = iter;
         st->nslot = nslot;
-        st->sched_j = j + 1u;
+        st->sched_j = j + st->sched_stride;
         st->iterations += nslot;
     }
 }
@@ -326,9 +330,9 @@ hipError_t launch_bounce(hipStream_t s, const KParams &p, const LaunchCfg &cfg, 
                            bounce_lds_bytes(p, cfg), s);
 }
 
-hipError_t launch_iter_set(hipStream_t s, IterState *st, uint32_t iter_first, uint32_t q, uint32_t r)
+hipError_t launch_iter_set(hipStream_t s, IterState *st, uint32_t iter_first, uint32_t q, uint32_t r, uint32_t j0, uint32_t stride)
 {
-    hipLaunchKernelGGL(k_iter_set, dim3(1), dim3(1), 0, s, st, iter_first, q, r);
+    hipLaunchKernelGGL(k_iter_set, dim3(1), dim3(1), 0, s, st, iter_first, q, r, j0, stride);
     return hipGetLastError();
 }
 

@@ -255,28 +255,37 @@ int pt_multi_gather_to_device(pt_multi *m, void *device_rgb, int dst_device)
     if (rc != PT_OK) return rc;
     if (m->strip > 0 && n > 1) return copy_strips(m, nullptr, device_rgb, dst_device, /*to_frame=*/true);
     std::vector<hipStream_t> streams((size_t)n, nullptr);
+    // every exit below goes through `finish`: streams created so far are drained and destroyed on error paths too
+    auto finish = [&](int code) {
+        for (int k = 0; k < n; ++k) {
+            if (!streams[(size_t)k]) continue;
+            (void)hipSetDevice(m->device[(size_t)k]);
+            const hipError_t e = hipStreamSynchronize(streams[(size_t)k]);
+            (void)hipStreamDestroy(streams[(size_t)k]);
+            streams[(size_t)k] = nullptr;
+            if (e != hipSuccess && code == PT_OK) code = pt::fail(PT_ERR_HIP, "pt_multi_gather_to_device: %s", hipGetErrorString(e));
+        }
+        return code;
+    };
     for (int k = 0; k < n; ++k) {
         int r0, r1;
         band(m->height, n, k, &r0, &r1);
         const size_t bytes = (size_t)(r1 - r0) * (size_t)m->width * 3 * sizeof(float);
         void *src = nullptr;
         rc = pt_image_device_pointer(m->ctx[(size_t)k], &src);
-        if (rc != PT_OK) return rc;
+        if (rc != PT_OK) return finish(rc);
         char *dst = (char *)device_rgb + (size_t)r0 * (size_t)m->width * 3 * sizeof(float);
-        if (hipSetDevice(m->device[(size_t)k]) != hipSuccess) return pt::fail(PT_ERR_HIP, "pt_multi_gather_to_device: %s", hipGetErrorString(hipGetLastError()));
-        if (hipStreamCreateWithFlags(&streams[(size_t)k], hipStreamNonBlocking) != hipSuccess) return pt::fail(PT_ERR_HIP, "pt_multi_gather_to_device: %s", hipGetErrorString(hipGetLastError()));
+        if (hipSetDevice(m->device[(size_t)k]) != hipSuccess) return finish(pt::fail(PT_ERR_HIP, "pt_multi_gather_to_device: %s", hipGetErrorString(hipGetLastError())));
+        if (hipStreamCreateWithFlags(&streams[(size_t)k], hipStreamNonBlocking) != hipSuccess) {
+            streams[(size_t)k] = nullptr;
+            return finish(pt::fail(PT_ERR_HIP, "pt_multi_gather_to_device: %s", hipGetErrorString(hipGetLastError())));
+        }
         hipError_t e = (m->device[(size_t)k] == dst_device)
                            ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, streams[(size_t)k])
                            : hipMemcpyPeerAsync(dst, dst_device, src, m->device[(size_t)k], bytes, streams[(size_t)k]);
-        if (e != hipSuccess) return pt::fail(PT_ERR_HIP, "pt_multi_gather_to_device: %s", hipGetErrorString(e));
+        if (e != hipSuccess) return finish(pt::fail(PT_ERR_HIP, "pt_multi_gather_to_device: %s", hipGetErrorString(e)));
     }
-    for (int k = 0; k < n; ++k) {
-        (void)hipSetDevice(m->device[(size_t)k]);
-        hipError_t e = hipStreamSynchronize(streams[(size_t)k]);
-        (void)hipStreamDestroy(streams[(size_t)k]);
-        if (e != hipSuccess) return pt::fail(PT_ERR_HIP, "pt_multi_gather_to_device: %s", hipGetErrorString(e));
-    }
-    return PT_OK;
+    return finish(PT_OK);
 }
 
 // sendImageToPBO for a single-device handle (the PBO is a device pointer of the GL device)

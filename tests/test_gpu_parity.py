@@ -150,6 +150,41 @@ def test_iteration_batching_is_invisible(pkg, batch):
     assert st.iterations == iters
 
 
+@pytest.mark.parametrize("batch,iters", [(16, 37), (4, 11), (1, 5), (16, 16), (3, 12)])
+def test_launch_sequences_in_flight_are_invisible(pkg, batch, iters):
+    """pt_options.sequences = 2: batch n + 1 renders on a second stream (own ray pools, planes, counters) beside batch n;
+    only the accumulates are ordered, in iteration order, so image, counts and stats are those of one sequence -- also
+    for odd batch counts (the second sequence gets one batch fewer) and calls of a single batch."""
+    a, la, sa = gpu_render(pkg, "sampleScene_spec.txt", 121, 67, 5, iters=iters, batch=batch, rr_start=2, sequences=1)
+    b, lb, sb = gpu_render(pkg, "sampleScene_spec.txt", 121, 67, 5, iters=iters, batch=batch, rr_start=2, sequences=2)
+    c, lc = cpu_render("sampleScene_spec.txt", 121, 67, 5, iters=iters, rr_start=2)
+    check(b, c, lb, lc, f"sequences=2 batch={batch}")
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and la == lb
+    assert sa.iterations == sb.iterations == iters
+
+
+def test_launch_sequences_across_calls_and_features(pkg):
+    """Two sequences in flight over several pt_render calls (resume), with direct lighting (planes accumulate along the
+    path) and on the batched walk: same bits as the oracle."""
+    sc = pkg.SceneFile(os.path.join(SCENES, "sampleScene_spec.txt"))
+    sc.set_resolution(96, 64)
+    with pkg.Renderer(0) as r:
+        r.set_options(depth=4, batch=2, sequences=2, direct_light=1)
+        r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
+        r.set_camera(sc.camera)
+        r.clear_image()
+        r.render(1, 5)
+        r.render(6, 1)
+        r.render(7, 6)
+        img = r.download_image()
+        st = r.stats()
+    c, lc = cpu_render("sampleScene_spec.txt", 96, 64, 4, iters=12, direct_light=1)
+    check(img, c, [int(x) for x in st.live_in[:4]], lc, "sequences=2 over three calls, direct lighting")
+    g, lg, _ = gpu_render(pkg, "cloud256.txt", 160, 90, 6, iters=9, batch=2, sequences=2, rotat=1)
+    c2, lc2 = cpu_render("cloud256.txt", 160, 90, 6, iters=9, rotat=1)
+    check(g, c2, lg, lc2, "sequences=2 on the batched walk")
+
+
 def test_resume_from_host_image(pkg):
     """(image, iteration) is a complete state: 1..3 then 4..6 from the downloaded image == 1..6."""
     full, lf, _ = gpu_render(pkg, "sampleScene.txt", 96, 64, 4, iters=6)
@@ -776,6 +811,91 @@ def test_scene_spanning_triangles(pkg, geom_path, tmp_path):
     base, _ = O.render(osc.geoms, osc.n_objects - 1, osc.mats, osc.n_materials, osc.camera, depth, iters=iters,
                        meshes={i: m for i, m in osc.meshes.items() if i < osc.n_objects - 1})
     assert not np.array_equal(base, c)                    # the quad is in the picture
+
+
+def test_large_mesh_configures_in_seconds(pkg, tmp_path):
+    """A 131 072-triangle height field: the hierarchy build is O(n log n) (binned surface-area splits above 4 096
+    primitives per node; the full sweep used to copy the index vector at every cost improvement: minutes at this size),
+    the 4-wide node copy no longer fits the LDS (geom_path 8 by the library's own choice), and sample pixels agree with
+    the oracle's brute-force loop."""
+    import time
+    n = 256
+    xs = np.linspace(-0.5, 0.5, n + 1, dtype=np.float32)
+    gx, gz = np.meshgrid(xs, xs, indexing="ij")
+    gy = (0.05 * np.sin(9.0 * gx) * np.cos(7.0 * gz)).astype(np.float32)
+    P = np.stack([gx, gy, gz], axis=-1)
+    a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+    tris = np.concatenate([np.stack([a, c, b], axis=2), np.stack([a, d, c], axis=2)], axis=0).reshape(-1, 9).astype(np.float32)
+    assert tris.shape[0] == 2 * n * n
+    text = open(os.path.join(SCENES, "mesh_cornell.txt")).read().rstrip("\n")
+    (tmp_path / "meshes").mkdir()
+    for f in os.listdir(os.path.join(SCENES, "meshes")):
+        (tmp_path / "meshes" / f).write_bytes(open(os.path.join(SCENES, "meshes", f), "rb").read())
+    (tmp_path / "meshes" / "empty.obj").write_text("v 0 0 0\n")
+    text += "\n\nOBJECT 10\nmeshes/empty.obj\nmaterial 1\nframe 0\nTRANS 0 2.5 0\nROTAT 0 0 0\nSCALE 8 8 8\n"
+    path = tmp_path / "field.txt"
+    path.write_text(text)
+    W, H, depth = 64, 48, 3
+    sc = pkg.SceneFile(str(path), 1)
+    sc.set_resolution(W, H)
+    meshes = dict(sc.meshes)
+    meshes[sc.n_objects - 1] = tris
+    with pkg.Renderer(0) as r:
+        r.set_options(depth=depth)
+        r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
+        r.set_meshes(meshes)
+        r.set_camera(sc.camera)
+        t0 = time.perf_counter()
+        r.clear_image()                                  # configures: hierarchy build, camera-ray lists
+        dt = time.perf_counter() - t0
+        r.render(1, 1)
+        g = r.download_image()
+        st = r.stats()
+    print(f"configure with {tris.shape[0]} triangles: {dt:.2f} s")
+    assert dt < 20.0
+    osc = O.LoadedScene(str(path), 1)
+    osc.set_resolution(W, H)
+    om = dict(osc.meshes)
+    om[osc.n_objects - 1] = tris
+    opt = O.Options(depth, -1, 0, O.TRIG_POLY)
+    ex, keep = O.make_extras(om, None, None, osc.n_objects)
+    L = O.lib()
+    rng = np.random.default_rng(5)
+    for _ in range(96):                                  # the oracle tests every triangle: sample pixels
+        x, y = int(rng.integers(W)), int(rng.integers(H))
+        l = np.array(L.o_trace_path_ex(osc.geoms, osc.n_objects, osc.mats, osc.n_materials, C.byref(osc.camera), C.byref(opt),
+                                       C.byref(ex), x, y, 1, None).tup(), np.float32)
+        assert np.array_equal(g[y, x].view(np.uint32), l.view(np.uint32)), f"pixel ({x},{y}): {g[y, x]} vs {l}"
+    del keep
+    assert int(st.live_in[0]) == W * H
+
+
+def test_contexts_do_not_leak_device_memory(pkg):
+    """create / configure / render / destroy in a loop (the batched walk with camera-ray lists, motion blur's child
+    contexts, two launch sequences): the device's free memory comes back (pt_destroy once forgot the span tables)."""
+    import torch
+    sc = pkg.SceneFile(os.path.join(SCENES, "cloud256.txt"), 1)
+    sc.set_resolution(128, 64)
+    nxt = pkg.SceneFile(os.path.join(SCENES, "cloud256.txt"), 1)
+
+    def once(motion):
+        with pkg.Renderer(0) as r:
+            r.set_options(depth=3, batch=2)
+            r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
+            r.set_camera(sc.camera)
+            if motion:
+                r.set_motion(nxt.geoms, None, 3, 1)
+            r.clear_image()
+            r.render(1, 5)
+            r.synchronize()
+    once(True)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for k in range(12):
+        once(k % 3 == 0)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(0)[0]
+    assert free0 - free1 < (8 << 20), f"{(free0 - free1) / 2**20:.1f} MiB of device memory lost over 12 contexts"
 
 
 def test_triangle_meshes_with_options_and_errors(pkg):
