@@ -101,8 +101,10 @@ typedef struct pt_options {
                              their samples are folded into the running mean in iteration order, so the image does not
                              depend on it */
     int direct_light;     /* 1 = sample the lights explicitly at every diffuse vertex (one shadow ray; the reference's
-                             getRandomPointOnCube / getRandomPointOnSphere samplers, ref: src/intersections.h:133-182) and
-                             do not count a light hit by chance after such a vertex; 0 = pure path tracing (default).
+                             getRandomPointOnCube / getRandomPointOnSphere samplers, ref: src/intersections.h:133-182; an
+                             emissive MESH geom is one light: area-weighted triangle pick + uniform point) and do not count
+                             a light of the table hit by chance after such a vertex; 0 = pure path tracing (default).
+                             The table holds the first 16 emissive geoms; further emitters are reached by chance only.
                              Needs compaction 1. */
     int absorption;       /* 1 = Beer-Lambert absorption (material ABSCOEFF) over path segments that end on the inner side of
                              a refractive surface: calculateTransmission, ref stub src/interactions.h:31-33; 0 = off (default) */
@@ -229,8 +231,9 @@ enum {
     PT_KAT_TRANSMISSION = 14,   /* in: absorption[3], distance                   out: rgb transmittance    ref src/interactions.h:31-33 */
     PT_KAT_SAMPLE_LIGHT = 15,   /* in: type (bits), transform[16], seed          out: p[3], n[3]           direct lighting sampler */
     PT_KAT_LOG = 16,            /* in: x                                         out: ln(x)                deterministic log of the free-flight sampler */
-    PT_KAT_SCATTER = 17         /* in: o[3], d[3], depth, absorption[3], rsct, T[3], u1, u2, u3
+    PT_KAT_SCATTER = 17,        /* in: o[3], d[3], depth, absorption[3], rsct, T[3], u1, u2, u3
                                    out: scattered (0/1), o[3], d[3], depth, T[3]                           ref src/interactions.h:36-39 */
+    PT_KAT_SAMPLE_TRIANGLE = 18 /* in: v0[3], e1[3], e2[3], u_a, u_b                 out: p[3], area         mesh-light sampler (direct lighting) */
 };
 int  pt_device_kat(pt_ctx *ctx, int op, const float *in, int n_in, float *out, int n_out);
 

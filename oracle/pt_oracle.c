@@ -711,21 +711,70 @@ static int nearest_hit(const o_staticGeom *geoms, int nG, const tri_table *tt, o
 }
 
 /* spec: one path.  Returns the radiance sample L_i of this iteration. */
-typedef struct { int n; int prim[O_MAX_LIGHTS]; float area[O_MAX_LIGHTS]; } light_table;
+/* Light table.  Entry j is an emissive sphere / cube (tri_count 0, prim = its index) or an emissive MESH geom as a whole
+ * (prim = the geom; its triangles of positive area, in primitive order, are tris[tri_first .. tri_first + tri_count) with
+ * the running fp32 sum of their areas in cdf[]; area = that sum's last value).  sampled[i] = primitive i (geoms, then
+ * triangles) belongs to an entry: only those are left to the explicit sampling when hit by chance. */
+typedef struct {
+    int n; int prim[O_MAX_LIGHTS]; float area[O_MAX_LIGHTS]; int tri_first[O_MAX_LIGHTS], tri_count[O_MAX_LIGHTS];
+    int *tris; float *cdf; unsigned char *sampled;
+} light_table;
 
-/* spec (DESIGN.md "Direct lighting"): emissive primitives in list order, at most O_MAX_LIGHTS */
-static void collect_lights(const o_staticGeom *geoms, int nG, const o_material *mats, light_table *lt)
+/* spec: area of a world-space triangle (e1, e2 = its edges from v0), fp32 */
+float o_triangleArea(o_vec3 e1, o_vec3 e2) { return 0.5f * length3(cross3(e1, e2)); }
+
+/* spec: uniform point on the triangle v0, v0 + e1, v0 + e2 from two uniform numbers (square-root parametrisation) */
+o_vec3 o_sampleTriangle(o_vec3 v0, o_vec3 e1, o_vec3 e2, float u_a, float u_b)
 {
-    lt->n = 0;
+    float s = sqrtf(u_a);
+    float a = s * (1.0f - u_b), b = s * u_b;
+    return add3(add3(v0, scale3(a, e1)), scale3(b, e2));
+}
+
+/* spec (DESIGN.md "Direct lighting"): emissive geoms in list order, at most O_MAX_LIGHTS entries; a MESH geom is one
+ * entry made of its triangles (area-weighted pick, then a uniform point: the reference names the triangle as an optional
+ * primitive, src/intersections.h:79, and its samplers take (geom, float seed), :133,179) */
+static int collect_lights(const o_staticGeom *geoms, int nG, const o_material *mats, const tri_table *tt, light_table *lt)
+{
+    lt->n = 0; lt->tris = NULL; lt->cdf = NULL; lt->sampled = NULL;
+    const int ntri = tt ? tt->n : 0;
+    lt->sampled = (unsigned char *)calloc((size_t)(nG + ntri) + 1, 1);
+    if (ntri > 0) {
+        lt->tris = (int *)malloc((size_t)ntri * sizeof(int));
+        lt->cdf = (float *)malloc((size_t)ntri * sizeof(float));
+    }
+    if (!lt->sampled || (ntri > 0 && (!lt->tris || !lt->cdf))) return -5;
+    int used = 0;
     for (int i = 0; i < nG && lt->n < O_MAX_LIGHTS; i++) {
-        if (geoms[i].type == O_MESH) continue;
-        if (mats[geoms[i].materialid].emittance > 0.0f) {
+        if (!(mats[geoms[i].materialid].emittance > 0.0f)) continue;
+        if (geoms[i].type != O_MESH) {
             lt->prim[lt->n] = i;
             lt->area[lt->n] = o_lightArea(&geoms[i]);
+            lt->tri_first[lt->n] = 0; lt->tri_count[lt->n] = 0;
+            lt->sampled[i] = 1;
             lt->n++;
+            continue;
         }
+        float acc = 0.0f;
+        const int first = used;
+        for (int k = 0; k < ntri; k++) {
+            if (tt->geom[k] != i) continue;
+            const float *w = tt->w + 12 * (size_t)k;
+            const float a = o_triangleArea(v3(w[3], w[4], w[5]), v3(w[6], w[7], w[8]));
+            if (!(a > 0.0f)) continue;
+            acc = acc + a;
+            lt->tris[used] = k; lt->cdf[used] = acc; used++;
+            lt->sampled[nG + k] = 1;
+        }
+        if (used == first) continue;                              /* no surface: not a light */
+        lt->prim[lt->n] = i;
+        lt->area[lt->n] = acc;
+        lt->tri_first[lt->n] = first; lt->tri_count[lt->n] = used - first;
+        lt->n++;
     }
+    return 0;
 }
+static void free_lights(light_table *lt) { free(lt->tris); free(lt->cdf); free(lt->sampled); lt->tris = NULL; lt->cdf = NULL; lt->sampled = NULL; }
 
 static o_vec3 trace_path(const o_staticGeom *geoms, int nG, const tri_table *tt, const o_material *mats, const cam_basis *cb,
                          const o_options *opt, const light_table *lt, int W, int x, int y, unsigned iteration,
@@ -753,7 +802,8 @@ static o_vec3 trace_path(const o_staticGeom *geoms, int nG, const tri_table *tt,
         const o_staticGeom *hg = (hit < nG) ? &geoms[hit] : &geoms[tt->geom[hit - nG]];   /* triangle: its MESH geom */
         const o_material *m = &mats[hg->materialid];
         if (m->emittance > 0.0f) {                                 /* light: emit and stop */
-            if (!suppress) L = add3(L, scale3(m->emittance, mul3(T, m->color)));
+            /* (an emitter the explicit sampling does not cover -- beyond the table's O_MAX_LIGHTS entries -- still counts) */
+            if (!(suppress && lt->sampled[hit])) L = add3(L, scale3(m->emittance, mul3(T, m->color)));
             break;
         }
         if (b == opt->depth - 1 && !nee) break;                    /* depth exhausted: no contribution */
@@ -774,10 +824,29 @@ static o_vec3 trace_path(const o_staticGeom *geoms, int nG, const tri_table *tt,
             if (j > lt->n - 1) j = lt->n - 1;
             const o_staticGeom *lg = &geoms[lt->prim[j]];
             o_vec3 yl, nl;
-            o_sampleLight(lg, u_seed * 16777216.0f, &yl, &nl);
+            int lprim = lt->prim[j];                               /* the primitive the shadow ray must reach */
             o_vec3 nf = (dot3(n, r.direction) > 0.0f) ? neg3(n) : n;
             o_ray sr;
             sr.origin = add3(p, scale3(O_RAY_BIAS_AMOUNT, nf));
+            if (lt->tri_count[j] > 0) {
+                /* mesh light: the float-seeded engine of the reference's samplers draws the triangle (by area: first one
+                 * whose running area exceeds u_t * total, else the last) and a uniform point on it; triangles emit from
+                 * both sides, so the normal is taken on the side that faces the shading point */
+                unsigned lr; o_minstd_seed(&lr, o_hash((unsigned)(u_seed * 16777216.0f)));
+                float u_t = o_uniform_real(&lr, 0, 1), u_a = o_uniform_real(&lr, 0, 1), u_b = o_uniform_real(&lr, 0, 1);
+                const float *cdf = lt->cdf + lt->tri_first[j];
+                float target = u_t * lt->area[j];
+                int lo = 0, hi = lt->tri_count[j] - 1;
+                while (lo < hi) { int mid = (lo + hi) >> 1; if (cdf[mid] > target) hi = mid; else lo = mid + 1; }
+                const int k = lt->tris[lt->tri_first[j] + lo];
+                const float *w = tt->w + 12 * (size_t)k;
+                yl = o_sampleTriangle(v3(w[0], w[1], w[2]), v3(w[3], w[4], w[5]), v3(w[6], w[7], w[8]), u_a, u_b);
+                nl = v3(w[9], w[10], w[11]);
+                if (dot3(nl, sub3(yl, sr.origin)) > 0.0f) nl = neg3(nl);
+                lprim = nG + k;
+            } else {
+                o_sampleLight(lg, u_seed * 16777216.0f, &yl, &nl);
+            }
             o_vec3 wi = sub3(yl, sr.origin);
             float d2 = dot3(wi, wi);
             float dist = sqrtf(d2);
@@ -788,7 +857,7 @@ static o_vec3 trace_path(const o_staticGeom *geoms, int nG, const tri_table *tt,
                 o_vec3 hp, hn; float ht;
                 int hs = nearest_hit(geoms, nG, tt, sr, &hp, &hn, &ht);
                 float tol = 1e-3f * ((dist > 1.0f) ? dist : 1.0f);
-                if (hs == lt->prim[j] && fabsf(ht - dist) <= tol) {
+                if (hs == lprim && fabsf(ht - dist) <= tol) {
                     const o_material *lm = &mats[lg->materialid];
                     float G = (cx * cy) / d2;
                     float wgt = (G * (lt->area[j] * (float)lt->n)) * 0.318309886f;
@@ -881,14 +950,15 @@ static int build_states(const o_staticGeom *geoms, int nG, const o_material *mat
         st[k].geoms = sliced ? ex->slice_geoms + (size_t)k * (size_t)nG : geoms;
         const o_cameraData *c = (sliced && ex->slice_cams) ? &ex->slice_cams[k] : cam;
         st[k].cb = camera_basis(cam->resolution, c->position, c->view, c->up, cam->fov);
-        collect_lights(st[k].geoms, nG, mats, &st[k].lt);
+        st[k].lt.tris = NULL; st[k].lt.cdf = NULL; st[k].lt.sampled = NULL;
         int rc = build_tri_table(st[k].geoms, nG, ex, &st[k].tt);
-        if (rc != 0) { for (int j = 0; j <= k; j++) free_tri_table(&st[j].tt); free(st); return rc; }
+        if (rc == 0) rc = collect_lights(st[k].geoms, nG, mats, &st[k].tt, &st[k].lt);
+        if (rc != 0) { for (int j = 0; j <= k; j++) { free_tri_table(&st[j].tt); free_lights(&st[j].lt); } free(st); return rc; }
     }
     *out = st;
     return 0;
 }
-static void free_states(scene_state *st, int n) { for (int k = 0; k < n; k++) free_tri_table(&st[k].tt); free(st); }
+static void free_states(scene_state *st, int n) { for (int k = 0; k < n; k++) { free_tri_table(&st[k].tt); free_lights(&st[k].lt); } free(st); }
 static const scene_state *state_of(const scene_state *st, int n, unsigned iteration)
 {
     return &st[n > 1 ? (int)(((iteration - 1u) / (unsigned)O_SLICE_ITERATIONS) % (unsigned)n) : 0];

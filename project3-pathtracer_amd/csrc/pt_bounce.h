@@ -1299,7 +1299,11 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                 const uint32_t m = h.material;
                 const float emit = s_mats[M_EMIT * p.nM + m];
                 if (emit > 0.0f) {
-                    if (!NEE || (pix >> 31) == 0u) {
+                    // (direct lighting: a light the previous vertex could have sampled adds nothing when hit by chance;
+                    // an emitter outside the light table -- Prim::area is 0 for those -- still counts)
+                    bool counts = true;
+                    if (NEE && (pix >> 31) != 0u) counts = !((PRIMS_IN_LDS ? s_prims[h.prim].area : p.prims[h.prim].area) > 0.0f);
+                    if (counts) {
                         const f3 col = mk(s_mats[M_CR * p.nM + m], s_mats[M_CG * p.nM + m], s_mats[M_CB * p.nM + m]);
                         L = emit * (T * col);
                     }
@@ -1326,13 +1330,37 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                         const float u_seed = u01_of(minstd_jump(s0, MINSTD_A6));
                         int j = (int)(u_light * (float)p.nlights);
                         if (j > p.nlights - 1) j = p.nlights - 1;
-                        lprim = (uint32_t)p.lights[j];
+                        const int4 lr = *reinterpret_cast<const int4 *>(p.lights + j);      // prim, tri_first, tri_count, area
+                        const float larea = __int_as_float(lr.w);
+                        so = h.p + 0.0002f * nf;
+                        f3 yl, nl;
+                        uint32_t lmat;
+                        if (lr.z > 0) {
+                            // mesh light: the float-seeded engine draws the triangle (first one whose running area exceeds
+                            // u_t * total, else the last) and a uniform point on it; the normal faces the shading point
+                            uint32_t rng = minstd_seed(wang_hash((uint32_t)(u_seed * 16777216.0f)));
+                            const float u_t = uniform_real(rng, 0, 1), u_a = uniform_real(rng, 0, 1), u_b = uniform_real(rng, 0, 1);
+                            const float *cdf = p.light_cdf + lr.y;
+                            const float target = u_t * larea;
+                            int lo = 0, hi = lr.z - 1;
+                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] > target) hi = mid; else lo = mid + 1; }
+                            lprim = (uint32_t)(p.ngeoms + p.light_tris[lr.y + lo]);
+                            const Prim *LP = &p.prims[lprim];                           // (triangles never sit in the LDS copies)
+                            const float4 *tw = reinterpret_cast<const float4 *>(LP->inv);
+                            const float4 t0 = tw[0], t1 = tw[1], t2 = tw[2];           // v0.xyz e1.x | e1.yz e2.xy | e2.z ...
+                            const f3 v0 = mk(t0.x, t0.y, t0.z), e1 = mk(t0.w, t1.x, t1.y), e2 = mk(t1.z, t1.w, t2.x);
+                            yl = sampleTriangle(v0, e1, e2, u_a, u_b);
+                            nl = mk(LP->fwd[0], LP->fwd[1], LP->fwd[2]);
+                            if (dot(nl, yl - so) > 0.0f) nl = -nl;
+                            lmat = LP->material;
+                        } else {
+                        lprim = (uint32_t)lr.x;
                         const Prim *LP = PRIMS_IN_LDS ? &s_prims[lprim] : &p.prims[lprim];
                         const uint4 hd = *reinterpret_cast<const uint4 *>(LP);           // type, material, area, pad
                         const float4 *fw = reinterpret_cast<const float4 *>(LP->fwd);
                         const float4 f0 = fw[0], f1 = fw[1], f2 = fw[2], cc = fw[3];   // fwd rows, (cx, cy, cz, bound)
                         const float fwd[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
-                        f3 yl, nl;
+                        lmat = hd.y;
                         if (hd.x == 1u) {                            // cube light: thresholds and face normals from the table
                             const float4 *tab = PRIMS_IN_LDS ? reinterpret_cast<const float4 *>(s_prims + p.nG) + lprim * 9u
                                                              : reinterpret_cast<const float4 *>(p.face_n) + lprim * 8u;
@@ -1340,7 +1368,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                         } else {
                             sampleLight(hd.x, fwd, mk(cc.x, cc.y, cc.z), u_seed * 16777216.0f, yl, nl);
                         }
-                        so = h.p + 0.0002f * nf;
+                        }
                         const f3 wi = yl - so;
                         const float d2 = dot(wi, wi);
                         ldist = sqrt_rn(d2);
@@ -1349,8 +1377,8 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                         if (cx > 0.0f && cy > 0.0f) {
                             want_shadow = true;
                             const float G = (cx * cy) / d2;
-                            const float wgt = (G * (__uint_as_float(hd.z) * (float)p.nlights)) * 0.318309886f;
-                            const uint32_t lm = hd.y;
+                            const float wgt = (G * (larea * (float)p.nlights)) * 0.318309886f;
+                            const uint32_t lm = lmat;
                             const f3 col = mk(s_mats[M_CR * p.nM + m], s_mats[M_CG * p.nM + m], s_mats[M_CB * p.nM + m]);
                             const f3 lcol = mk(s_mats[M_CR * p.nM + lm], s_mats[M_CG * p.nM + lm], s_mats[M_CB * p.nM + lm]);
                             Ld = wgt * ((T * col) * (s_mats[M_EMIT * p.nM + lm] * lcol));

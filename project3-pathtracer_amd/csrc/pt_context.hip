@@ -99,7 +99,9 @@ struct pt_ctx {
     uint32_t *d_span_mask = nullptr;
     size_t span_mask_cap = 0;
     float *d_box_world = nullptr;
-    int *d_lights = nullptr;    // direct lighting: indices of the emissive primitives
+    pt::LightRec *d_lights = nullptr;    // direct lighting: the light table
+    int *d_light_tris = nullptr;         //   mesh lights: triangle numbers ...
+    float *d_light_cdf = nullptr;        //   ... and the running sums of their areas
     ptd::BvhNode *d_bvh = nullptr;
     float *d_bvh4 = nullptr;    // 4-wide hierarchy (geom_path 7)
     float *d_image_own = nullptr;
@@ -513,12 +515,35 @@ int configure(pt_ctx *c)
             p.cx = (float)cx; p.cy = (float)cy; p.cz = (float)cz;
             p.bound_r2 = (float)(rad * rad);
         }
-        // direct lighting: emissive primitives in list order (at most 16), their surface area from getRadiuses'
-        // half-extents (ref: src/intersections.h:120-129) in fp32 with the sampler's own operation order
-        std::vector<int> lights;
+        // direct lighting: the light table -- emissive geoms in list order (at most 16 entries).  A sphere / cube is an
+        // entry with its surface area from getRadiuses' half-extents (ref: src/intersections.h:120-129) in fp32 with the
+        // sampler's own operation order; an emissive MESH geom is ONE entry made of its triangles of positive area
+        // (area-weighted pick by the running fp32 sum of 0.5 |e1 x e2|, then a uniform point).  Prim::area > 0 marks the
+        // primitives the table covers: only those are left to the explicit sampling when a path hits them by chance.
+        std::vector<pt::LightRec> lights;
+        std::vector<int> ltris;
+        std::vector<float> lcdf;
         for (size_t i = 0; i < c->geoms.size() && lights.size() < 16; ++i) {
             const pt_static_geom &g = c->geoms[i];
-            if (g.type == PT_MESH || !(c->mats[(size_t)g.materialid].emittance > 0.0f)) continue;
+            if (!(c->mats[(size_t)g.materialid].emittance > 0.0f)) continue;
+            if (g.type == PT_MESH) {
+                float acc = 0.0f;
+                const size_t first = ltris.size();
+                for (size_t t = 0; t < nT; ++t) {
+                    if (c->tri_geom[t] != (int)i) continue;
+                    const float *w = &triw[12 * t];
+                    const v3 cr = cross3(v3{w[3], w[4], w[5]}, v3{w[6], w[7], w[8]});
+                    const float a = 0.5f * sqrtf(cr.x * cr.x + cr.y * cr.y + cr.z * cr.z);
+                    if (!(a > 0.0f)) continue;
+                    acc = acc + a;
+                    ltris.push_back((int)t);
+                    lcdf.push_back(acc);
+                    prims[nGeoms + t].area = a;
+                }
+                if (ltris.size() == first) continue;          // no surface: not a light
+                lights.push_back(pt::LightRec{(int)i, (int)first, (int)(ltris.size() - first), acc});
+                continue;
+            }
             const pt_mat4 &m = g.transform;
             auto mv = [&](float x, float y, float z, float out[3]) {
                 out[0] = (m.x.x * x) + (m.x.y * y) + (m.x.z * z) + (m.x.w * 1.0f);
@@ -539,15 +564,26 @@ int configure(pt_ctx *c)
                 area = 4.18879020478639098f * ((r[0] * r[1] + r[0] * r[2]) + r[1] * r[2]);
             }
             prims[i].area = area;
-            lights.push_back((int)i);
+            lights.push_back(pt::LightRec{(int)i, 0, 0, area});
         }
         k.nlights = o.direct_light ? (int)lights.size() : 0;
+        k.ngeoms = (int)nGeoms;
         k.absorption = o.absorption ? 1 : 0;
         k.scatter = o.scatter ? 1 : 0;
         if (c->d_lights) { (void)hipFree(c->d_lights); c->d_lights = nullptr; }
-        HIP_TRY(hipMalloc((void **)&c->d_lights, (lights.size() ? lights.size() : 1) * sizeof(int)));
-        if (!lights.empty()) HIP_TRY(hipMemcpy(c->d_lights, lights.data(), lights.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (c->d_light_tris) { (void)hipFree(c->d_light_tris); c->d_light_tris = nullptr; }
+        if (c->d_light_cdf) { (void)hipFree(c->d_light_cdf); c->d_light_cdf = nullptr; }
+        HIP_TRY(hipMalloc((void **)&c->d_lights, (lights.size() ? lights.size() : 1) * sizeof(pt::LightRec)));
+        if (!lights.empty()) HIP_TRY(hipMemcpy(c->d_lights, lights.data(), lights.size() * sizeof(pt::LightRec), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&c->d_light_tris, (ltris.size() ? ltris.size() : 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void **)&c->d_light_cdf, (lcdf.size() ? lcdf.size() : 1) * sizeof(float)));
+        if (!ltris.empty()) {
+            HIP_TRY(hipMemcpy(c->d_light_tris, ltris.data(), ltris.size() * sizeof(int), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(c->d_light_cdf, lcdf.data(), lcdf.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         k.lights = c->d_lights;
+        k.light_tris = c->d_light_tris;
+        k.light_cdf = c->d_light_cdf;
 
         if (c->d_prims) { (void)hipFree(c->d_prims); c->d_prims = nullptr; }
         HIP_TRY(hipMalloc((void **)&c->d_prims, prims.size() * sizeof(ptd::Prim)));
@@ -1245,6 +1281,8 @@ void pt_destroy(pt_ctx *c)
     if (c->d_span_mask) (void)hipFree(c->d_span_mask);
     if (c->d_box_world) (void)hipFree(c->d_box_world);
     if (c->d_lights) (void)hipFree(c->d_lights);
+    if (c->d_light_tris) (void)hipFree(c->d_light_tris);
+    if (c->d_light_cdf) (void)hipFree(c->d_light_cdf);
     if (c->d_bvh) (void)hipFree(c->d_bvh);
     if (c->d_bvh4) (void)hipFree(c->d_bvh4);
     if (c->d_image_own) (void)hipFree(c->d_image_own);
@@ -1616,8 +1654,8 @@ int pt_device_kat(pt_ctx *c, int op, const float *in, int n_in, float *out, int 
 {
     if (!c || !in || !out || n_in < 1 || n_out < 1 || n_in > 4096 || n_out > 4096)
         return fail(PT_ERR_INVALID, "pt_device_kat: bad arguments");
-    static const int need_in[] = {0, 1, 1, 5, 39, 5, 16, 17, 17, 20, 7, 6, 8, 11, 4, 18, 1, 17};
-    if (op < 1 || op > 17 || n_in < need_in[op]) return fail(PT_ERR_INVALID, "pt_device_kat: op %d needs %d inputs", op, op >= 1 && op <= 17 ? need_in[op] : 0);
+    static const int need_in[] = {0, 1, 1, 5, 39, 5, 16, 17, 17, 20, 7, 6, 8, 11, 4, 18, 1, 17, 11};
+    if (op < 1 || op > 18 || n_in < need_in[op]) return fail(PT_ERR_INVALID, "pt_device_kat: op %d needs %d inputs", op, op >= 1 && op <= 18 ? need_in[op] : 0);
     HIP_TRY(hipSetDevice(c->device));
     float *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, (size_t)(n_in + n_out) * sizeof(float)));

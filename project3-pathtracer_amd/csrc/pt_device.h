@@ -608,6 +608,16 @@ __device__ __forceinline__ void sampleCubeLightTab(const float *fwd, const float
     normal = mk(n.x, n.y, n.z);
 }
 
+// mesh lights (direct lighting): a uniform point on the triangle v0, v0 + e1, v0 + e2 from two uniform numbers
+// (square-root parametrisation) and the triangle's area; same operations as the oracle's o_sampleTriangle / o_triangleArea
+__device__ __forceinline__ f3 sampleTriangle(f3 v0, f3 e1, f3 e2, float u_a, float u_b)
+{
+    const float sq = sqrt_rn(u_a);
+    const float ba = sq * (1.0f - u_b), bb = sq * u_b;
+    return (v0 + ba * e1) + bb * e2;
+}
+__device__ __forceinline__ float triangleArea(f3 e1, f3 e2) { return 0.5f * length(cross(e1, e2)); }
+
 // Direct lighting: a point on a light and the geometric normal there, from one float seed (the reference's sampler
 // interface).  Normals as the intersection tests define them (boxNormal / sphereNormal).
 __device__ __forceinline__ void sampleLight(uint32_t type, const float *fwd, f3 center, float randomSeed, f3 &point, f3 &normal)

@@ -48,6 +48,11 @@ struct IterState {
     unsigned long long dbg[8];                   // hierarchy-walk diagnostics (DEBUG_BVH builds only)
 };
 
+// direct lighting: one entry of the light table -- an emissive sphere / cube (tri_count 0, prim = its index) or an emissive
+// MESH geom as a whole: its triangles of positive area are light_tris[tri_first .. tri_first + tri_count) (triangle numbers,
+// primitive index = number of geoms + that), light_cdf[] beside them holds the running fp32 sum of their areas
+struct LightRec { int prim; int tri_first; int tri_count; float area; };
+
 struct KParams {
     // camera basis (host-side part of raycastFromCameraKernel)
     float eye[3], M[3], H[3], V[3];
@@ -97,8 +102,11 @@ struct KParams {
     uint32_t w_shift;
     int absorption;        // 1 = Beer-Lambert absorption inside refractive objects (material planes M_AR..M_AB)
     int scatter;           // 1 = subsurface random walk inside SCATTER materials (material planes M_SCAT, M_RSCT)
-    int nlights;           // direct lighting: emissive primitives (0 = feature off), indices in `lights`
-    const int *lights;
+    int nlights;           // direct lighting: entries of the light table (0 = feature off)
+    const LightRec *lights;
+    const int *light_tris;     // mesh lights: triangle numbers and the running sum of their areas, per entry
+    const float *light_cdf;
+    int ngeoms;            // geoms among the nG primitives (= nG - ntri): primitive index of triangle t = ngeoms + t
 };
 
 struct LaunchCfg {

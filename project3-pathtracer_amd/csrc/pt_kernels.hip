@@ -117,6 +117,12 @@ __global__ void k_device_kat(int op, const float *in, float *out, int n_out)
         put3(8, T);
         break;
     }
+    case PT_KAT_SAMPLE_TRIANGLE: {
+        const f3 v0 = mk(in[0], in[1], in[2]), e1 = mk(in[3], in[4], in[5]), e2 = mk(in[6], in[7], in[8]);
+        put3(0, sampleTriangle(v0, e1, e2, in[9], in[10]));
+        out[3] = triangleArea(e1, e2);
+        break;
+    }
     default: break;
     }
 }

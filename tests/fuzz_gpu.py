@@ -62,9 +62,15 @@ def main():
         if rng.random() < 0.2:
             # a MESH object with a handful of random triangles (object space), placed like any other object
             nt = int(rng.integers(1, 40))
-            geoms.append(O.make_geom(O.MESH, int(rng.integers(0, 4)), rng.uniform(-4, 4, 3), rng.uniform(-3.2, 3.2, 3), rng.uniform(0.5, 4.0, 3)))
+            # (material 4 is the light's: the mesh is then an entry of the light table -- sampled by triangle when direct
+            # lighting is on -- and some scenes get more emissive geoms than the table's 16 entries)
+            geoms.append(O.make_geom(O.MESH, int(rng.integers(0, 5)), rng.uniform(-4, 4, 3), rng.uniform(-3.2, 3.2, 3), rng.uniform(0.5, 4.0, 3)))
             meshes = {len(geoms) - 1: rng.uniform(-0.5, 0.5, (nt, 9)).astype(np.float32)}
             gopts["geom_path"] = int(rng.choice([0, 1, 7, 8]))
+        if rng.random() < 0.1:
+            for g in geoms[2:min(len(geoms), 24)]:          # many small emitters: the light table overflows past 16
+                if g.type != O.MESH and rng.random() < 0.8:
+                    g.materialid = 4
         strip = None
         if rng.random() < 0.3 and H >= 4:
             world = int(rng.integers(2, 4))

@@ -147,6 +147,8 @@ def lib():
                             C.c_void_p, P(C.c_ulonglong), i]),
         "o_trace_path_ex": (Vec3, [P(StaticGeom), i, P(Material), i, P(CameraData), P(Options), P(Extras), i, i, u, P(i)]),
         "o_load_obj": (i, [C.c_char_p, P(P(f)), P(i)]),
+        "o_triangleArea": (f, [Vec3, Vec3]),
+        "o_sampleTriangle": (Vec3, [Vec3, Vec3, Vec3, f, f]),
         "o_interpolateGeom": (StaticGeom, [P(StaticGeom), P(StaticGeom), f, i]),
         "o_interpolateCamera": (CameraData, [P(CameraData), P(CameraData), f]),
         "o_sliceTime": (f, [i, i]),

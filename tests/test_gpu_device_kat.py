@@ -197,3 +197,21 @@ def test_log_and_scatter_step_against_oracle(gpu):
         out = gpu.device_kat(SCATTER, o + d + [depth] + sa + [rsct] + T + u, 11)
         assert int(out[0]) == sc
         assert_bits(out[1:11], r.origin.tup() + r.direction.tup() + (dep.value,) + col.tup(), "calculateScatterAndAbsorption")
+
+
+SAMPLE_TRIANGLE = 18
+
+
+def test_triangle_sampler_against_oracle(gpu):
+    """Mesh lights: the device's uniform point on a triangle and its area == o_sampleTriangle / o_triangleArea, bit for bit."""
+    L = O.lib()
+    rng = np.random.default_rng(18)
+    for k in range(300):
+        v0, e1, e2 = ([float(np.float32(v)) for v in rng.uniform(-5, 5, 3)] for _ in range(3))
+        ua, ub = float(np.float32(rng.random())), float(np.float32(rng.random()))
+        if k % 60 == 0:
+            ua, ub = (0.0, 1.0) if k % 120 == 0 else (1.0, 0.0)
+        out = gpu.device_kat(SAMPLE_TRIANGLE, v0 + e1 + e2 + [ua, ub], 4)
+        p = L.o_sampleTriangle(O.v3(v0), O.v3(e1), O.v3(e2), ua, ub)
+        assert_bits(out[:3], p.tup(), "sampleTriangle")
+        assert_bits(out[3], L.o_triangleArea(O.v3(e1), O.v3(e2)), "triangleArea")

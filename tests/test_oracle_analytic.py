@@ -340,6 +340,87 @@ def test_direct_lighting_estimates_the_same_image():
     assert np.mean((b16 - ref) ** 2) < 0.5 * np.mean((a16 - ref) ** 2)
 
 
+def test_triangle_sampler_is_uniform():
+    """o_sampleTriangle: every point lies in the triangle, the sample mean is the centroid and each of the four
+    medial sub-triangles receives a quarter of the points; o_triangleArea is half the cross product's length."""
+    L = O.lib()
+    v0, e1, e2 = (1.0, 2.0, 3.0), (2.0, 0.0, 1.0), (0.0, 3.0, -1.0)
+    assert abs(L.o_triangleArea(O.v3(e1), O.v3(e2)) - 0.5 * np.linalg.norm(np.cross(e1, e2))) < 1e-6
+    rng = np.random.default_rng(3)
+    n = 20000
+    uv = rng.random((n, 2)).astype(np.float32)
+    E = np.stack([e1, e2], axis=1)
+    bary = np.empty((n, 2))
+    for k in range(n):
+        p = np.array(L.o_sampleTriangle(O.v3(v0), O.v3(e1), O.v3(e2), float(uv[k, 0]), float(uv[k, 1])).tup()) - np.array(v0)
+        bary[k] = np.linalg.lstsq(E, p, rcond=None)[0]
+    a, b = bary[:, 0], bary[:, 1]
+    assert (a >= -1e-6).all() and (b >= -1e-6).all() and (a + b <= 1 + 1e-6).all()
+    assert abs(a.mean() - 1 / 3) < 0.01 and abs(b.mean() - 1 / 3) < 0.01
+    quarter = [(a > 0.5), (b > 0.5), (a + b < 0.5), (a <= 0.5) & (b <= 0.5) & (a + b >= 0.5)]
+    for q in quarter:
+        assert abs(q.mean() - 0.25) < 0.015
+
+
+def _room_with_mesh_light(with_cube_light):
+    """Diffuse floor and back wall, an emissive two-triangle quad above the floor, optionally a cube light beside it."""
+    mats = [O.make_material(color=(0.8, 0.8, 0.8)), O.make_material(color=(1, 1, 1), emittance=6.0),
+            O.make_material(color=(1, 0.9, 0.8), emittance=4.0)]
+    geoms = [O.make_geom(O.CUBE, 0, (0, -0.05, 0), (0, 0, 0), (12, 0.1, 12)),
+             O.make_geom(O.CUBE, 0, (0, 3, -4), (0, 0, 0), (12, 6, 0.1)),
+             O.make_geom(O.MESH, 1, (-1.0, 3.0, 0.0), (0.3, 0.2, 0.1), (2.5, 1, 2.5))]
+    if with_cube_light:
+        geoms.append(O.make_geom(O.CUBE, 2, (2.5, 2.0, 0.5), (0, 0.4, 0), (0.8, 0.8, 0.8)))
+    quad = np.array([[-0.5, 0, -0.5, 0.5, 0, -0.5, 0.5, 0, 0.5], [-0.5, 0, -0.5, 0.5, 0, 0.5, -0.5, 0, 0.5]], dtype=np.float32)
+    ga = (O.StaticGeom * len(geoms))(*geoms)
+    ma = (O.Material * len(mats))(*mats)
+    cam = O.make_camera(32, 24, (0, 2.0, 9), (0, -0.1, -1), (0, 1, 0), 25)
+    return ga, len(geoms), ma, len(mats), cam, {2: quad}
+
+
+@pytest.mark.parametrize("with_cube_light", [False, True])
+def test_mesh_lights_are_sampled_explicitly(with_cube_light):
+    """An emissive MESH geom is a light of the table: with explicit sampling (d vertices + a connection) the frame mean
+    equals pure path tracing with d + 1 bounces -- also beside a cube light (round 2 dropped the mesh's light at
+    diffuse vertices in that case: it was suppressed as "sampled" without being in the table)."""
+    ga, nG, ma, nM, cam, meshes = _room_with_mesh_light(with_cube_light)
+    a, _ = O.render(ga, nG, ma, nM, cam, 3, iters=1200, meshes=meshes)
+    sh = []
+    b, _ = O.render(ga, nG, ma, nM, cam, 2, iters=1200, meshes=meshes, direct_light=1, shadow_out=sh)
+    assert sh[0] > 0
+    m_a, m_b = a.mean(axis=(0, 1)), b.mean(axis=(0, 1))
+    assert m_a.min() > 0.05
+    assert np.all(np.abs(m_a - m_b) <= 0.03 * m_a), (m_a, m_b)
+    # lower variance with the explicit connection
+    ref, _ = O.render(ga, nG, ma, nM, cam, 2, iters=4000, meshes=meshes, direct_light=1, seed=11)
+    a8, _ = O.render(ga, nG, ma, nM, cam, 3, iters=8, meshes=meshes)
+    b8, _ = O.render(ga, nG, ma, nM, cam, 2, iters=8, meshes=meshes, direct_light=1)
+    assert np.mean((b8 - ref) ** 2) < 0.6 * np.mean((a8 - ref) ** 2)
+
+
+def test_emitters_beyond_the_light_table_still_count():
+    """The table holds 16 entries; a 17th emitter is reached by chance only, and such a hit is NOT suppressed after a
+    diffuse vertex (it would otherwise contribute nothing at all): means with and without explicit sampling agree."""
+    mats = [O.make_material(color=(0.8, 0.8, 0.8)), O.make_material(color=(1, 1, 1), emittance=3.0)]
+    geoms = [O.make_geom(O.CUBE, 0, (0, -0.05, 0), (0, 0, 0), (14, 0.1, 14))]
+    for k in range(17):
+        geoms.append(O.make_geom(O.SPHERE, 1, (-4.0 + 0.5 * k, 1.5 + 0.1 * (k % 3), -1.0 + 0.3 * (k % 4)), (0, 0, 0), (0.4, 0.4, 0.4)))
+    geoms[-1] = O.make_geom(O.SPHERE, 1, (0.0, 4.0, 1.0), (0, 0, 0), (2.5, 2.5, 2.5))      # the 17th: large, off the table
+    ga = (O.StaticGeom * len(geoms))(*geoms)
+    ma = (O.Material * len(mats))(*mats)
+    cam = O.make_camera(24, 16, (0, 2.5, 10), (0, -0.15, -1), (0, 1, 0), 25)
+    a, _ = O.render(ga, len(geoms), ma, 2, cam, 3, iters=1500)
+    b, _ = O.render(ga, len(geoms), ma, 2, cam, 2, iters=1500, direct_light=1)
+    m_a, m_b = a.mean(axis=(0, 1)), b.mean(axis=(0, 1))
+    # pure path tracing with d + 1 bounces sees what d vertices + connection see, except the big off-table sphere's light
+    # at the LAST vertex (no bounce left to reach it by chance): b is the smaller one, but far above "17th light ignored"
+    g17 = (O.StaticGeom * 17)(*geoms[:17])
+    c, _ = O.render(g17, 17, ma, 2, cam, 2, iters=1500, direct_light=1)
+    m_c = c.mean(axis=(0, 1))
+    assert np.all(m_b > 1.5 * m_c), (m_b, m_c)
+    assert np.all(m_b <= 1.03 * m_a)
+
+
 def test_direct_lighting_off_without_lights_or_flag():
     sc = O.LoadedScene(os.path.join(SCENES, "sampleScene.txt"), 1)
     sc.set_resolution(24, 24)
