@@ -122,6 +122,12 @@ typedef struct pt_options {
                              pt_render call renders on a second stream, with ray pools of its own, while batch n does -- its
                              launches fill the compute units the tail of every bounce launch leaves idle; only the accumulates
                              are ordered (iteration order), so the image does not depend on it */
+    int motion_per_ray;   /* motion blur (pt_set_motion): 0 = one scene state per run of 16 iterations (default, every scene);
+                             1 = a shutter time PER RAY: every path draws its time as the third number of its camera stream
+                             and sees, at all bounces, matrices (and camera vectors) interpolated entry-wise between the two
+                             of `slices` + 1 knot states around it -- exact for translations, a chord approximation of
+                             rotations that tightens with `slices`.  Scalar geometry path only (geom_path 0 or 1); excludes
+                             meshes, direct lighting and scattering */
 } pt_options;
 
 typedef struct pt_stats {
@@ -170,7 +176,10 @@ int  pt_set_stream(pt_ctx *ctx, void *hip_stream);    /* render on a caller-owne
  * matrices rebuilt as the loader does (rotat_units: PT_ROTAT_*); iterations are dealt to the slices in runs of
  * PT_SLICE_ITERATIONS: iteration i renders slice ((i - 1) / PT_SLICE_ITERATIONS) % slices, so every launch sequence still
  * sees one static scene and the running mean converges to the time average.  cam_next = NULL: the camera is at rest.
- * slices <= 1 or geoms_next = NULL turns it off.  Call after pt_set_scene / pt_set_camera (pt_set_scene drops it). */
+ * With pt_options.motion_per_ray the same call gives the two frames and `slices` (>= 1) is the number of linear segments
+ * between slices + 1 knot states at shutter times k / slices.
+ * geoms_next = NULL, slices < 1 (or slices == 1 without motion_per_ray) turns it off.  Call after pt_set_scene /
+ * pt_set_camera (pt_set_scene drops it). */
 #define PT_SLICE_ITERATIONS 16
 int  pt_set_motion(pt_ctx *ctx, const pt_static_geom *geoms_next_frame, const pt_camera_data *cam_next_frame_or_null,
                    int slices, int rotat_units);

@@ -776,13 +776,60 @@ static int collect_lights(const o_staticGeom *geoms, int nG, const o_material *m
 }
 static void free_lights(light_table *lt) { free(lt->tris); free(lt->cdf); free(lt->sampled); lt->tris = NULL; lt->cdf = NULL; lt->sampled = NULL; }
 
+/* per-ray motion blur: the knots of the shutter interval and scratch room for one path's interpolated scene */
+typedef struct {
+    int n_knots; const o_staticGeom *knot_geoms; const o_cameraData *knot_cams; o_vec2 resolution, fov;
+    o_staticGeom *scratch;        /* nG entries, private to the calling thread */
+} motion_knots;
+
+static float lerp1f(float a, float b, float f) { return a + (b - a) * f; }
+static o_vec3 lerp3f(o_vec3 a, o_vec3 b, float f) { return v3(lerp1f(a.x, b.x, f), lerp1f(a.y, b.y, f), lerp1f(a.z, b.z, f)); }
+static o_vec4 lerp4f(o_vec4 a, o_vec4 b, float f) { o_vec4 r; r.x = lerp1f(a.x, b.x, f); r.y = lerp1f(a.y, b.y, f); r.z = lerp1f(a.z, b.z, f); r.w = lerp1f(a.w, b.w, f); return r; }
+
+/* spec (per-ray motion blur): the scene a path with shutter draw u_t sees -- segment k = min(floor(u_t * K), K - 1) of the
+ * K = n_knots - 1 between the knots, f = u_t * K - k, rows 0..2 of both matrices (and the camera vectors) a + (b - a) * f */
+static void scene_at_time(const motion_knots *mk, int nG, float u_t, o_staticGeom *out, cam_basis *cb, const o_cameraData *cam0)
+{
+    const int K = mk->n_knots - 1;
+    const float tau = u_t * (float)K;
+    int k = (int)tau;
+    if (k > K - 1) k = K - 1;
+    const float f = tau - (float)k;
+    const o_staticGeom *A = mk->knot_geoms + (size_t)k * (size_t)nG, *B = A + nG;
+    for (int g = 0; g < nG; g++) {
+        out[g] = A[g];
+        out[g].transform.x = lerp4f(A[g].transform.x, B[g].transform.x, f);
+        out[g].transform.y = lerp4f(A[g].transform.y, B[g].transform.y, f);
+        out[g].transform.z = lerp4f(A[g].transform.z, B[g].transform.z, f);
+        out[g].inverseTransform.x = lerp4f(A[g].inverseTransform.x, B[g].inverseTransform.x, f);
+        out[g].inverseTransform.y = lerp4f(A[g].inverseTransform.y, B[g].inverseTransform.y, f);
+        out[g].inverseTransform.z = lerp4f(A[g].inverseTransform.z, B[g].inverseTransform.z, f);
+    }
+    if (mk->knot_cams) {
+        const o_cameraData *ca = &mk->knot_cams[k], *cn = ca + 1;
+        *cb = camera_basis(mk->resolution, lerp3f(ca->position, cn->position, f), lerp3f(ca->view, cn->view, f),
+                           lerp3f(ca->up, cn->up, f), mk->fov);
+    } else {
+        *cb = camera_basis(mk->resolution, cam0->position, cam0->view, cam0->up, mk->fov);
+    }
+}
+
 static o_vec3 trace_path(const o_staticGeom *geoms, int nG, const tri_table *tt, const o_material *mats, const cam_basis *cb,
                          const o_options *opt, const light_table *lt, int W, int x, int y, unsigned iteration,
-                         int *bounces, unsigned long long *live_in, unsigned long long *shadow_rays)
+                         int *bounces, unsigned long long *live_in, unsigned long long *shadow_rays,
+                         const motion_knots *mk, const o_cameraData *cam0)
 {
     unsigned pixel = (unsigned)x + (unsigned)y * (unsigned)W;
     unsigned rng; o_minstd_seed(&rng, o_stream_seed(pixel, iteration, 0u, opt->seed));
     float jx = o_u01(&rng), jy = o_u01(&rng);
+    cam_basis cb_t;
+    if (mk) {
+        /* the path's shutter time: third draw of the camera stream; its whole scene is interpolated once */
+        float u_t = o_u01(&rng);
+        scene_at_time(mk, nG, u_t, mk->scratch, &cb_t, cam0);
+        geoms = mk->scratch;
+        cb = &cb_t;
+    }
     o_ray r = camera_ray(cb, x, y, jx, jy);
     if (opt->lens_radius > 0.0f) {
         float u1 = o_u01(&rng), u2 = o_u01(&rng);
@@ -964,16 +1011,37 @@ static const scene_state *state_of(const scene_state *st, int n, unsigned iterat
     return &st[n > 1 ? (int)(((iteration - 1u) / (unsigned)O_SLICE_ITERATIONS) % (unsigned)n) : 0];
 }
 
+/* per-ray motion blur asked for?  0 = no, 1 = yes, < 0 = invalid combination */
+static int motion_mode(const o_extras *ex, const o_options *opt, const o_staticGeom *geoms, int nG)
+{
+    if (!ex || ex->n_knots == 0) return 0;
+    if (ex->n_knots < 2 || !ex->knot_geoms) return -7;
+    if (ex->n_slices > 0 || ex->n_meshes > 0 || opt->direct_light || opt->scatter) return -7;
+    for (int i = 0; i < nG; i++) if (geoms[i].type == O_MESH) return -7;
+    return 1;
+}
+
 o_vec3 o_trace_path_ex(const o_staticGeom *geoms, int nG, const o_material *mats, int nM, const o_cameraData *cam,
                        const o_options *opt, const o_extras *ex, int x, int y, unsigned iteration, int *bounces_out)
 {
     if (validate(geoms, nG, nM, cam, opt) != 0) return v3(-1, -1, -1);
+    const int mm = motion_mode(ex, opt, geoms, nG);
+    if (mm < 0) return v3(-1, -1, -1);
     scene_state *st;
     if (build_states(geoms, nG, mats, cam, ex, &st) != 0) return v3(-1, -1, -1);
     const int n = n_states(ex);
     const scene_state *s = state_of(st, n, iteration);
     if (bounces_out) *bounces_out = 0;
-    o_vec3 L = trace_path(s->geoms, nG, &s->tt, mats, &s->cb, opt, &s->lt, (int)cam->resolution.x, x, y, iteration, bounces_out, NULL, NULL);
+    motion_knots mk;
+    if (mm) {
+        mk.n_knots = ex->n_knots; mk.knot_geoms = ex->knot_geoms; mk.knot_cams = ex->knot_cams;
+        mk.resolution = cam->resolution; mk.fov = cam->fov;
+        mk.scratch = (o_staticGeom *)malloc((size_t)(nG > 0 ? nG : 1) * sizeof(o_staticGeom));
+        if (!mk.scratch) { free_states(st, n); return v3(-1, -1, -1); }
+    }
+    o_vec3 L = trace_path(s->geoms, nG, &s->tt, mats, &s->cb, opt, &s->lt, (int)cam->resolution.x, x, y, iteration, bounces_out, NULL, NULL,
+                          mm ? &mk : NULL, cam);
+    if (mm) free(mk.scratch);
     free_states(st, n);
     return L;
 }
@@ -989,6 +1057,7 @@ typedef struct {
     float *image; int W, H; int iter_first, iter_count; int row0, row1;
     unsigned long long *live_in;   /* private per thread, depth entries */
     unsigned long long shadow_rays;
+    const motion_knots *mk; const o_cameraData *cam0;   /* per-ray motion blur (mk->scratch private per thread), else NULL */
 } job;
 
 static void *render_rows(void *arg)
@@ -999,7 +1068,7 @@ static void *render_rows(void *arg)
         for (int y = j->row0; y < j->row1; y++) {
             for (int x = 0; x < j->W; x++) {
                 o_vec3 L = trace_path(s->geoms, j->nG, &s->tt, j->mats, &s->cb, j->opt, &s->lt, j->W, x, y, (unsigned)it,
-                                      NULL, j->live_in, &j->shadow_rays);
+                                      NULL, j->live_in, &j->shadow_rays, j->mk, j->cam0);
                 /* spec: running mean, stateless given (image, iteration) */
                 float *px = &j->image[3 * ((size_t)x + (size_t)y * (size_t)j->W)];
                 float fi = (float)it, fim1 = (float)(it - 1);
@@ -1033,6 +1102,8 @@ int o_render_ex(const o_staticGeom *geoms, int nG, const o_material *mats, int n
     int rc = validate(geoms, nG, nM, cam, opt);
     if (rc != 0) return rc;
     if (!image || iter_first < 1 || iter_count < 0) return -4;
+    const int mm = motion_mode(ex, opt, geoms, nG);
+    if (mm < 0) return mm;
     int W = (int)cam->resolution.x, H = (int)cam->resolution.y;
     scene_state *states;
     rc = build_states(geoms, nG, mats, cam, ex, &states);
@@ -1043,8 +1114,15 @@ int o_render_ex(const o_staticGeom *geoms, int nG, const o_material *mats, int n
     if (nthreads > 256) nthreads = 256;
 
     job jobs[256]; pthread_t th[256];
+    motion_knots *mkt = NULL;
+    o_staticGeom *scratch = NULL;
+    if (mm) {
+        mkt = (motion_knots *)malloc((size_t)nthreads * sizeof(motion_knots));
+        scratch = (o_staticGeom *)malloc((size_t)nthreads * (size_t)(nG > 0 ? nG : 1) * sizeof(o_staticGeom));
+        if (!mkt || !scratch) { free(mkt); free(scratch); free_states(states, ns); return -5; }
+    }
     unsigned long long *counts = (unsigned long long *)calloc((size_t)nthreads * (size_t)opt->depth, sizeof(*counts));
-    if (!counts) { free_states(states, ns); return -5; }
+    if (!counts) { free(mkt); free(scratch); free_states(states, ns); return -5; }
     /* rows are dealt in contiguous blocks; each pixel is owned by exactly one thread */
     for (int t = 0; t < nthreads; t++) {
         job *j = &jobs[t];
@@ -1053,6 +1131,13 @@ int o_render_ex(const o_staticGeom *geoms, int nG, const o_material *mats, int n
         j->row0 = (int)((long long)H * t / nthreads); j->row1 = (int)((long long)H * (t + 1) / nthreads);
         j->live_in = counts + (size_t)t * (size_t)opt->depth;
         j->shadow_rays = 0;
+        j->mk = NULL; j->cam0 = cam;
+        if (mm) {
+            mkt[t].n_knots = ex->n_knots; mkt[t].knot_geoms = ex->knot_geoms; mkt[t].knot_cams = ex->knot_cams;
+            mkt[t].resolution = cam->resolution; mkt[t].fov = cam->fov;
+            mkt[t].scratch = scratch + (size_t)t * (size_t)(nG > 0 ? nG : 1);
+            j->mk = &mkt[t];
+        }
     }
     if (nthreads == 1) render_rows(&jobs[0]);
     else {
@@ -1068,6 +1153,8 @@ int o_render_ex(const o_staticGeom *geoms, int nG, const o_material *mats, int n
     if (shadow_rays)
         for (int t = 0; t < nthreads; t++) *shadow_rays += jobs[t].shadow_rays;
     free(counts);
+    free(mkt);
+    free(scratch);
     free_states(states, ns);
     return 0;
 }

@@ -443,3 +443,5 @@ o_cameraData o_interpolateCamera(const o_cameraData *a, const o_cameraData *b, f
 
 /* shutter time of slice k of n: the middle of its interval, in fp32 */
 float o_sliceTime(int k, int n) { return ((float)k + 0.5f) / (float)n; }
+/* shutter time of knot k of n_knots (per-ray motion blur): both ends of the interval are knots */
+float o_knotTime(int k, int n_knots) { return (float)k / (float)(n_knots - 1); }

@@ -66,7 +66,7 @@ class Options(C.Structure):
                 ("workgroup", C.c_int), ("geom_path", C.c_int), ("row_begin", C.c_int), ("row_end", C.c_int),
                 ("use_graph", C.c_int), ("batch", C.c_int), ("direct_light", C.c_int), ("absorption", C.c_int), ("strip_rows", C.c_int), ("strip_world", C.c_int),
                 ("strip_rank", C.c_int), ("scatter", C.c_int), ("lens_radius", C.c_float), ("focal_distance", C.c_float),
-                ("sequences", C.c_int)]
+                ("sequences", C.c_int), ("motion_per_ray", C.c_int)]
 
 
 class Stats(C.Structure):

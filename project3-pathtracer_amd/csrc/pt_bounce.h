@@ -992,6 +992,72 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
     return h;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// FEAT_MOTION: a shutter time per ray
+// ---------------------------------------------------------------------------------------------------------------
+// Every path draws its time as the third number of its camera stream and sees the scene interpolated between the two
+// knot states around it: segment k of the nknots - 1 between the knots and the fraction f inside it.  Nothing about a
+// primitive is wave-uniform any more: each lane gathers the two knots' rows of the primitive and interpolates them
+// entry-wise, a + (b - a) * f (the oracle's scene_at_time).
+struct MotionTime { uint32_t k; float f; };
+__device__ __forceinline__ MotionTime motionTime(const KParams &p, float u_t)
+{
+    const int K = p.nknots - 1;
+    const float tau = u_t * (float)K;
+    int k = (int)tau;
+    if (k > K - 1) k = K - 1;
+    MotionTime mt;
+    mt.k = (uint32_t)k;
+    mt.f = tau - (float)k;
+    return mt;
+}
+// rows 0..2 of inverseTransform and transform of primitive g at the lane's time
+__device__ __forceinline__ void motionRows(const KParams &p, uint32_t g, MotionTime mt, float *inv, float *fwd)
+{
+    const float4 *A = reinterpret_cast<const float4 *>(p.knots) + ((size_t)mt.k * (size_t)p.nG + g) * 6u;
+    const float4 *B = A + (size_t)p.nG * 6u;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const float4 a = A[r], b = B[r];
+        float *dst = (r < 3) ? inv + 4 * r : fwd + 4 * (r - 3);
+        dst[0] = a.x + (b.x - a.x) * mt.f;
+        dst[1] = a.y + (b.y - a.y) * mt.f;
+        dst[2] = a.z + (b.z - a.z) * mt.f;
+        dst[3] = a.w + (b.w - a.w) * mt.f;
+    }
+}
+__device__ __forceinline__ Hit nearestHitMotion(const KParams &p, f3 o, f3 d, MotionTime mt)
+{
+    Hit h;
+    h.any = false;
+    h.material = 0;
+    h.prim = 0;
+    h.p = mk(0, 0, 0);
+    h.n = mk(0, 0, 0);
+    float best_t = 0.0f;
+    for (int g = 0; g < p.nG; ++g) {
+        const_u32_ptr hp = (const_u32_ptr)(uintptr_t)(p.prims + g);
+        const uint32_t type = hp[0], mat = hp[1];
+        if (type > 1u) continue;
+        Prim P;
+        P.type = type;
+        motionRows(p, (uint32_t)g, mt, P.inv, P.fwd);
+        P.cx = P.fwd[3]; P.cy = P.fwd[7]; P.cz = P.fwd[11];      // transform * (0,0,0,1): the translation column, exactly
+        f3 ip, in;
+        const float t = intersectPrim<false>(P, o, d, o, ip, in);
+        if (t > 0 && (!h.any || t < best_t)) {                    // smallest t > 0, ties keep the lowest index
+            h.any = true;
+            best_t = t;
+            h.p = ip;
+            h.n = in;
+            h.material = mat;
+            h.prim = (uint32_t)g;
+        }
+    }
+    h.t = best_t;
+    return h;
+}
+
 // nearest hit of (o, d) for the lanes with want == true, by the GEOM path.  Every lane of the wave must make the call
 // (the hit queue uses all 64 lanes as workers whatever their own ray).
 template <int GEOM, bool FIRST>
@@ -1058,11 +1124,12 @@ __device__ __forceinline__ uint32_t globalPixel(const KParams &p, uint32_t pl)
 // FEAT: optional features built as kernel instances of their own, so that the default path keeps its registers and
 // instruction count (measured: the scattering code alone costs the plain kernel 1.1 % when compiled in):
 // bit 0 = NEE (pt_options.direct_light), bit 1 = MEDIA (pt_options.scatter: subsurface random walk).
-enum { FEAT_NEE = 1, FEAT_MEDIA = 2 };
+// bit 2 = MOTION (pt_options.motion_per_ray: a shutter time per ray; scalar geometry path only).
+enum { FEAT_NEE = 1, FEAT_MEDIA = 2, FEAT_MOTION = 4 };
 template <int WG, bool FIRST, int GEOM, int COMPACT, int FEAT = 0>
 __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce(const KParams p, const int bounce)
 {
-    constexpr bool NEE = (FEAT & FEAT_NEE) != 0, MEDIA = (FEAT & FEAT_MEDIA) != 0;
+    constexpr bool NEE = (FEAT & FEAT_NEE) != 0, MEDIA = (FEAT & FEAT_MEDIA) != 0, MOTION = (FEAT & FEAT_MOTION) != 0;
     constexpr int NW = WG / 64;
     constexpr bool PRIMS_IN_LDS = (GEOM == GEOM_LDS || GEOM == GEOM_QUEUE || GEOM == GEOM_PAIR);   // GEOM_BVH gathers records from global memory (L1/L2)
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
@@ -1140,7 +1207,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
     __shared__ uint32_t s_key[MAXSLOT], s_key_cam[MAXSLOT];
     if (tid < MAXSLOT) {
         s_key[tid] = stream_key(iter + (uint32_t)tid, (uint32_t)bounce + 1u, p.seed);
-        if (FIRST) s_key_cam[tid] = stream_key(iter + (uint32_t)tid, 0u, p.seed);
+        if (FIRST || MOTION) s_key_cam[tid] = stream_key(iter + (uint32_t)tid, 0u, p.seed);
     }
     const uint32_t npix = (uint32_t)p.npix;
 
@@ -1192,6 +1259,9 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
         const uint32_t chunk_first_ray = (R * NW + wave) * 64u;   // (bounce 0: rays are numbered slot by slot, pixel by pixel)
         f3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(1, 1, 1);
         uint32_t pix = 0;
+        MotionTime mt;
+        mt.k = 0u;
+        mt.f = 0.0f;
         if (FIRST) {
             if (valid) {
                 // raycastFromCameraKernel: jittered pinhole ray through tile-local pixel pl of iteration slot
@@ -1222,9 +1292,27 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                 const float jy = u01_of(s);
                 const float sx = ((float)x + jx) / p.resx;
                 const float sy = ((float)y + jy) / p.resy;
-                const f3 eye = mk(p.eye[0], p.eye[1], p.eye[2]);
-                const f3 P = (mk(p.M[0], p.M[1], p.M[2]) + (1.0f - 2.0f * sx) * mk(p.H[0], p.H[1], p.H[2])) +
-                             (1.0f - 2.0f * sy) * mk(p.V[0], p.V[1], p.V[2]);
+                f3 eye = mk(p.eye[0], p.eye[1], p.eye[2]);
+                f3 cM = mk(p.M[0], p.M[1], p.M[2]), cH = mk(p.H[0], p.H[1], p.H[2]), cV = mk(p.V[0], p.V[1], p.V[2]);
+                f3 cA = mk(p.A[0], p.A[1], p.A[2]), cB = mk(p.B[0], p.B[1], p.B[2]), cvn = mk(p.vn[0], p.vn[1], p.vn[2]);
+                if (MOTION) {
+                    // the path's shutter time (third draw of the camera stream) and the camera basis at that time, with
+                    // the host's operation order (configure(): camera basis)
+                    s = minstd_next(s);
+                    mt = motionTime(p, u01_of(s));
+                    const float4 *ca = reinterpret_cast<const float4 *>(p.knot_cam) + mt.k * 3u, *cb = ca + 3;
+                    auto lerp4 = [&](float4 a, float4 b) { return mk(a.x + (b.x - a.x) * mt.f, a.y + (b.y - a.y) * mt.f, a.z + (b.z - a.z) * mt.f); };
+                    eye = lerp4(ca[0], cb[0]);
+                    const f3 view = lerp4(ca[1], cb[1]), up = lerp4(ca[2], cb[2]);
+                    cA = normalize(cross(view, up));
+                    cB = normalize(cross(cA, view));
+                    const float lenV = length(view);
+                    cM = eye + view;
+                    cH = (lenV * p.tan_x) * cA;
+                    cV = (lenV * p.tan_y) * cB;
+                    cvn = normalize(view);
+                }
+                const f3 P = (cM + (1.0f - 2.0f * sx) * cH) + (1.0f - 2.0f * sy) * cV;
                 o = eye;
                 d = normalize(P - eye);
                 if (p.lens_radius > 0.0f) {
@@ -1233,13 +1321,13 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                     const float u1 = u01_of(s);
                     s = minstd_next(s);
                     const float u2 = u01_of(s);
-                    const float tf = p.focal_distance / dot(d, mk(p.vn[0], p.vn[1], p.vn[2]));
+                    const float tf = p.focal_distance / dot(d, cvn);
                     const f3 Pf = eye + tf * d;
                     const float rr = p.lens_radius * sqrt_rn(u1);
                     const float around = (float)((double)u2 * 6.2831853071795864769252867665590057683943);
                     float sn, cs;
                     sincos_poly(around, sn, cs);
-                    o = eye + ((rr * cs) * mk(p.A[0], p.A[1], p.A[2]) + (rr * sn) * mk(p.B[0], p.B[1], p.B[2]));
+                    o = eye + ((rr * cs) * cA + (rr * sn) * cB);
                     d = normalize(Pf - o);
                 }
             }
@@ -1255,6 +1343,11 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                     o = mk(a.x, a.y, a.z);
                     d = mk(a.w, b.x, b.y);
                     T = mk(b.z, b.w, c.x);
+                    if (MOTION) {
+                        // the path's shutter time again: third draw of its camera stream (nothing is stored in the ray)
+                        const uint32_t sc = minstd_seed(wang_hash(globalPixel(p, pix & PIX_MASK) ^ s_key_cam[(pix >> SLOT_SHIFT) & (uint32_t)(MAXSLOT - 1)]));
+                        mt = motionTime(p, u01_of(minstd_jump(sc, MINSTD_A3)));
+                    }
                 }
             }
         }
@@ -1283,8 +1376,14 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
             while (b0 >= npix) b0 -= npix;
             primmask = b0 >> 6;                                           // (the batched walks take the span's number)
         }
-        const Hit h = (FIRST && p.lens_radius > 0.0f) ? nearestHit<GEOM, false>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane)
-                                                      : nearestHit<GEOM, FIRST>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane, primmask);
+        Hit h;
+        if (MOTION) {
+            h.any = false; h.material = 0; h.prim = 0; h.t = 0.0f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0);
+            if (valid) h = nearestHitMotion(p, o, d, mt);
+        } else {
+            h = (FIRST && p.lens_radius > 0.0f) ? nearestHit<GEOM, false>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane)
+                                                : nearestHit<GEOM, FIRST>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane, primmask);
+        }
         const unsigned long long c2 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
         f3 L = mk(0, 0, 0);               // radiance this vertex adds to the path's sample
         // direct lighting: the shadow ray this lane wants traced and what it is worth if the light is visible
@@ -1440,11 +1539,18 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                             // world units, more than the bias for objects scaled by > 2
                             nd = tdir;
                             bias_n = -nf;
+                            f3 v;
+                            if (MOTION) {
+                                float minv[12], mfwd[12];
+                                motionRows(p, h.prim, mt, minv, mfwd);
+                                v = mulMV(minv, d, 0.0f);
+                            } else {
                             const Prim *HP = PRIMS_IN_LDS ? &s_prims[h.prim] : &p.prims[h.prim];
                             const float4 *iv = reinterpret_cast<const float4 *>(HP->inv);
                             const float4 i0 = iv[0], i1 = iv[1], i2 = iv[2];
                             const float inv[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
-                            const f3 v = (HP->type == 3u) ? d : mulMV(inv, d, 0.0f);  // a triangle is tested in world space
+                            v = (HP->type == 3u) ? d : mulMV(inv, d, 0.0f);  // a triangle is tested in world space
+                            }
                             bias = 0.0002f + 1e-4f * rsqrt_rn(dot(v, v));
                         }
                     } else if (refl > 0.0f) {
@@ -1615,6 +1721,11 @@ static const void *bounce_fn_geom(bool first, int compact, int feat)
 {
     if (feat != 0) {
         if (compact != 1) return nullptr;
+        if (feat == FEAT_MOTION) {            // per-ray shutter time: the scalar path with 256-thread workgroups only
+            if constexpr (GEOM == GEOM_SCALAR && WG == 256) return bounce_fn_feat<256, GEOM_SCALAR, FEAT_MOTION>(first);
+            return nullptr;
+        }
+        if ((feat & FEAT_MOTION) != 0) return nullptr;
         if (feat == FEAT_NEE) return bounce_fn_feat<WG, GEOM, FEAT_NEE>(first);
         if (WG == 256 || WG == 512) {
             if (feat == FEAT_MEDIA) return bounce_fn_feat<(WG == 256 || WG == 512) ? WG : 256, GEOM, FEAT_MEDIA>(first);

@@ -100,6 +100,7 @@ struct pt_ctx {
     size_t span_mask_cap = 0;
     float *d_box_world = nullptr;
     pt::LightRec *d_lights = nullptr;    // direct lighting: the light table
+    float *d_knots = nullptr, *d_knot_cam = nullptr;   // per-ray motion blur: knot states (matrices, camera vectors)
     int *d_light_tris = nullptr;         //   mesh lights: triangle numbers ...
     float *d_light_cdf = nullptr;        //   ... and the running sums of their areas
     ptd::BvhNode *d_bvh = nullptr;
@@ -340,6 +341,12 @@ int build_wide4(const std::vector<ptd::BvhNode> &bin, const std::vector<int> &pt
     }
     return me;
 }
+
+// motion blur modes: one scene state per run of 16 iterations (child contexts), or a shutter time per ray
+bool motion_by_slices(const pt_ctx *c) { return c->motion_slices > 1 && !c->opt.motion_per_ray && !c->geoms_next.empty(); }
+bool motion_per_ray(const pt_ctx *c) { return c->motion_slices >= 1 && c->opt.motion_per_ray && !c->geoms_next.empty(); }
+float lerp1(float a, float b, float t);
+pt_vec3 lerp3(pt_vec3 a, pt_vec3 b, float t);
 
 // (re)build everything that depends on scene, camera or options
 int configure(pt_ctx *c)
@@ -693,6 +700,54 @@ int configure(pt_ctx *c)
         HIP_TRY(hipMalloc((void **)&c->d_mats, planes.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(c->d_mats, planes.data(), planes.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+    // motion blur with a shutter time per ray: knot states at shutter times j / slices, built as the slices are (TRS
+    // interpolated component-wise, matrices rebuilt by the loader's buildTransformationMatrix); the kernels interpolate the
+    // matrices and the camera vectors entry-wise between the two knots around a ray's time
+    k.nknots = 0;
+    if (motion_per_ray(c)) {
+        if (nT > 0) return fail(PT_ERR_INVALID, "motion_per_ray: triangle meshes need the slice scheme (motion_per_ray = 0)");
+        for (const pt_static_geom &g : c->geoms)
+            if (g.type == PT_MESH) return fail(PT_ERR_INVALID, "motion_per_ray: MESH objects need the slice scheme (motion_per_ray = 0)");
+        if (o.direct_light || o.scatter) return fail(PT_ERR_INVALID, "motion_per_ray excludes direct_light and scatter (use the slice scheme)");
+        if (o.compaction != 1) return fail(PT_ERR_INVALID, "motion_per_ray needs compaction 1 (got %d)", o.compaction);
+        if (!(o.geom_path == 0 || o.geom_path == 1)) return fail(PT_ERR_INVALID, "motion_per_ray runs on the scalar geometry path (geom_path 0 or 1, got %d)", o.geom_path);
+        if (!(o.workgroup == 0 || o.workgroup == 256)) return fail(PT_ERR_INVALID, "motion_per_ray needs workgroup 0 or 256 (got %d)", o.workgroup);
+        const int nk = c->motion_slices + 1;
+        std::vector<float> kn((size_t)nk * nGeoms * 24, 0.0f), kc((size_t)nk * 12, 0.0f);
+        for (int j = 0; j < nk; ++j) {
+            const float t = (float)j / (float)(nk - 1);
+            for (size_t i = 0; i < nGeoms; ++i) {
+                const pt_static_geom &a = c->geoms[i], &b = c->geoms_next[i];
+                pt_mat4 inv;
+                const pt_mat4 fwd = ptamd::buildTransformationMatrix(lerp3(a.translation, b.translation, t), lerp3(a.rotation, b.rotation, t),
+                                                                     lerp3(a.scale, b.scale, t), c->motion_rotat, &inv);
+                float *dst = &kn[((size_t)j * nGeoms + i) * 24];
+                memcpy(dst, &inv, 12 * sizeof(float));
+                memcpy(dst + 12, &fwd, 12 * sizeof(float));
+            }
+            const pt_camera_data &ca = c->cam;
+            const pt_camera_data &cb = c->have_cam_next ? c->cam_next : c->cam;
+            const pt_vec3 pos = c->have_cam_next ? lerp3(ca.position, cb.position, t) : ca.position;
+            const pt_vec3 view = c->have_cam_next ? lerp3(ca.view, cb.view, t) : ca.view;
+            const pt_vec3 up = c->have_cam_next ? lerp3(ca.up, cb.up, t) : ca.up;
+            float *cd = &kc[(size_t)j * 12];
+            cd[0] = pos.x; cd[1] = pos.y; cd[2] = pos.z;
+            cd[4] = view.x; cd[5] = view.y; cd[6] = view.z;
+            cd[8] = up.x; cd[9] = up.y; cd[10] = up.z;
+        }
+        if (c->d_knots) { (void)hipFree(c->d_knots); c->d_knots = nullptr; }
+        if (c->d_knot_cam) { (void)hipFree(c->d_knot_cam); c->d_knot_cam = nullptr; }
+        HIP_TRY(hipMalloc((void **)&c->d_knots, (kn.size() ? kn.size() : 1) * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&c->d_knot_cam, kc.size() * sizeof(float)));
+        if (!kn.empty()) HIP_TRY(hipMemcpy(c->d_knots, kn.data(), kn.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_knot_cam, kc.data(), kc.size() * sizeof(float), hipMemcpyHostToDevice));
+        k.knots = c->d_knots;
+        k.knot_cam = c->d_knot_cam;
+        k.nknots = nk;
+        const double PI = 3.1415926535897932384626422832795028841971;
+        k.tan_x = (float)tan((double)c->cam.fov.x * (PI / 180.0));
+        k.tan_y = (float)tan((double)c->cam.fov.y * (PI / 180.0));
+    }
     k.prims = c->d_prims;
     k.ro_eye = c->d_ro_eye;
     k.face_n = c->d_face_n;
@@ -801,6 +856,8 @@ int configure(pt_ctx *c)
     cfg.compact = o.compaction;
     cfg.nee = k.nlights > 0 ? 1 : 0;             // no lights: nothing to sample, the plain kernels are exact
     // the scattering kernels only when some material that can hold a medium asks for it: else the plain kernels are exact
+    cfg.motion = k.nknots > 0 ? 1 : 0;
+    if (cfg.motion) { cfg.geom = 0; cfg.workgroup = 256; cfg.nee = 0; }
     cfg.media = 0;
     if (k.scatter)
         for (const pt_material &m : c->mats)
@@ -1283,6 +1340,8 @@ void pt_destroy(pt_ctx *c)
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_light_tris) (void)hipFree(c->d_light_tris);
     if (c->d_light_cdf) (void)hipFree(c->d_light_cdf);
+    if (c->d_knots) (void)hipFree(c->d_knots);
+    if (c->d_knot_cam) (void)hipFree(c->d_knot_cam);
     if (c->d_bvh) (void)hipFree(c->d_bvh);
     if (c->d_bvh4) (void)hipFree(c->d_bvh4);
     if (c->d_image_own) (void)hipFree(c->d_image_own);
@@ -1320,12 +1379,13 @@ int pt_set_options(pt_ctx *c, const pt_options *o)
     if (o->scatter < 0 || o->scatter > 1) return fail(PT_ERR_INVALID, "scatter %d not 0 or 1", o->scatter);
     if (!(o->lens_radius >= 0.0f) || (o->lens_radius > 0.0f && !(o->focal_distance > 0.0f)))
         return fail(PT_ERR_INVALID, "lens radius %g / focal distance %g", (double)o->lens_radius, (double)o->focal_distance);
+    if (o->motion_per_ray < 0 || o->motion_per_ray > 1) return fail(PT_ERR_INVALID, "motion_per_ray %d not 0 or 1", o->motion_per_ray);
     if (o->sequences < 0 || o->sequences > PT_MAX_SEQUENCES) return fail(PT_ERR_INVALID, "sequences %d not in 0..%d", o->sequences, PT_MAX_SEQUENCES);
     if (o->direct_light && o->compaction != 1) return fail(PT_ERR_INVALID, "direct_light needs compaction 1 (got %d)", o->compaction);
     if (o->scatter && o->compaction != 1) return fail(PT_ERR_INVALID, "scatter needs compaction 1 (got %d)", o->compaction);
     c->opt = *o;
     c->dirty = true;
-    c->motion_dirty = c->motion_slices > 1;
+    c->motion_dirty = c->motion_slices >= 1;
     return PT_OK;
 }
 
@@ -1378,18 +1438,19 @@ int pt_set_meshes(pt_ctx *c, const pt_mesh *meshes, int n)
     c->tri_obj.swap(tri);
     c->tri_geom.swap(owner);
     c->dirty = true;
-    c->motion_dirty = c->motion_slices > 1;
+    c->motion_dirty = c->motion_slices >= 1;
     return PT_OK;
 }
 
 int pt_set_motion(pt_ctx *c, const pt_static_geom *geoms_next, const pt_camera_data *cam_next, int slices, int rotat_units)
 {
     if (!c) return fail(PT_ERR_INVALID, "pt_set_motion: NULL context");
-    if (slices <= 1 || !geoms_next) {                    // motion off
+    if (slices < 1 || !geoms_next) {                     // motion off
         c->motion_slices = 0;
         c->geoms_next.clear();
         c->have_cam_next = false;
         drop_slices(c);
+        c->dirty = true;
         return PT_OK;
     }
     if (!c->have_scene || !c->have_camera) return fail(PT_ERR_INVALID, "pt_set_motion: call pt_set_scene and pt_set_camera first");
@@ -1404,6 +1465,7 @@ int pt_set_motion(pt_ctx *c, const pt_static_geom *geoms_next, const pt_camera_d
     c->motion_slices = slices;
     c->motion_rotat = rotat_units;
     c->motion_dirty = true;
+    c->dirty = true;                                      // (per-ray mode: the knots are part of the configuration)
     return PT_OK;
 }
 
@@ -1415,7 +1477,7 @@ int pt_set_camera(pt_ctx *c, const pt_camera_data *cam)
     c->cam = *cam;
     c->have_camera = true;
     c->dirty = true;
-    c->motion_dirty = c->motion_slices > 1;
+    c->motion_dirty = c->motion_slices >= 1;
     return PT_OK;
 }
 
@@ -1500,7 +1562,8 @@ int pt_render(pt_ctx *c, int iter_first, int iter_count)
     if (rc != PT_OK) return rc;
     if (iter_count == 0) return PT_OK;
     hipStream_t s = c->stream;
-    if (c->motion_slices > 1) {
+    if (!motion_by_slices(c) && !c->slice_ctx.empty()) drop_slices(c);      // (left over from the slice scheme)
+    if (motion_by_slices(c)) {
         // motion blur: every run of PT_SLICE_ITERATIONS iterations belongs to one shutter slice, rendered by that
         // slice's context into this context's framebuffer (the running mean is stateless given image and iteration)
         rc = build_slices(c);
@@ -1601,7 +1664,7 @@ int pt_render_profiled(pt_ctx *c, int iter_first, int iter_count, double *bounce
 {
     if (!c || !bounce_ms_out) return fail(PT_ERR_INVALID, "pt_render_profiled: NULL argument");
     if (iter_first < 1 || iter_count < 0) return fail(PT_ERR_INVALID, "pt_render_profiled: iterations [%d,+%d)", iter_first, iter_count);
-    if (c->motion_slices > 1) return fail(PT_ERR_INVALID, "pt_render_profiled: not with motion blur (profile a slice's scene instead)");
+    if (motion_by_slices(c)) return fail(PT_ERR_INVALID, "pt_render_profiled: not with motion blur by slices (profile a slice's scene instead)");
     int rc = configure(c);
     if (rc != PT_OK) return rc;
     const int depth = c->kp.depth;

@@ -107,6 +107,11 @@ struct KParams {
     const int *light_tris;     // mesh lights: triangle numbers and the running sum of their areas, per entry
     const float *light_cdf;
     int ngeoms;            // geoms among the nG primitives (= nG - ntri): primitive index of triangle t = ngeoms + t
+    // motion blur with a shutter time per ray (FEAT_MOTION kernels): nknots scene states at shutter times k / (nknots - 1)
+    const float *knots;    // [nknots][nG][24]: inverse rows 0..2, forward rows 0..2 of every geom at every knot
+    const float *knot_cam; // [nknots][12]: camera position, view, up (xyz each, padded to 4)
+    int nknots;            // 0 = off
+    float tan_x, tan_y;    // tan of the half field-of-view angles (the per-ray camera basis is built on the device)
 };
 
 struct LaunchCfg {
@@ -117,6 +122,7 @@ struct LaunchCfg {
     int compact;     // 0 off, 1 per-wave sharded reservation, 2 workgroup scan + single counter
     int nee;         // 1 = explicit light sampling at diffuse vertices (compact must be 1)
     int media;       // 1 = subsurface random walk inside SCATTER materials (compact must be 1, workgroup 256 or 512)
+    int motion;      // 1 = per-ray shutter time (geom 0, workgroup 256, compact 1, neither nee nor media)
 };
 
 // kernels (pt_kernels.hip)

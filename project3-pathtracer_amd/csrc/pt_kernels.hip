@@ -295,14 +295,14 @@ const void *bounce_kernel_g7(int workgroup, bool first, int compact, int feat);
 static const void *select_bounce(const LaunchCfg &cfg, bool first)
 {
     switch (cfg.geom) {
-    case GEOM_SCALAR: return bounce_kernel_g0(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1));
-    case GEOM_LDS: return bounce_kernel_g1(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1));
-    case GEOM_QUEUE: return bounce_kernel_g2(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1));
-    case GEOM_BVH: return bounce_kernel_g3(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1));
-    case GEOM_PAIR: return bounce_kernel_g4(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1));
-    case GEOM_WALK_PAIR: return bounce_kernel_g5(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1));
-    case GEOM_WALK4: return bounce_kernel_g6(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1));
-    case GEOM_WALK4G: return bounce_kernel_g7(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1));
+    case GEOM_SCALAR: return bounce_kernel_g0(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1) | (cfg.motion << 2));
+    case GEOM_LDS: return bounce_kernel_g1(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1) | (cfg.motion << 2));
+    case GEOM_QUEUE: return bounce_kernel_g2(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1) | (cfg.motion << 2));
+    case GEOM_BVH: return bounce_kernel_g3(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1) | (cfg.motion << 2));
+    case GEOM_PAIR: return bounce_kernel_g4(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1) | (cfg.motion << 2));
+    case GEOM_WALK_PAIR: return bounce_kernel_g5(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1) | (cfg.motion << 2));
+    case GEOM_WALK4: return bounce_kernel_g6(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1) | (cfg.motion << 2));
+    case GEOM_WALK4G: return bounce_kernel_g7(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1) | (cfg.motion << 2));
     default: return nullptr;
     }
 }

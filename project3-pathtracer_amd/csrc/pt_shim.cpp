@@ -21,6 +21,8 @@
 //   PT_STRIP_ROWS (8)     with several devices: rows per interleaved strip (device k renders strips k, k+n, ...); 0 = one
 //                         contiguous band per device
 //   PT_MOTION_SLICES (0)  > 1: motion blur over the interval to the next animation frame, that many shutter slices
+//   PT_MOTION_PER_RAY (0) 1: a shutter time per ray instead (pt_options.motion_per_ray); PT_MOTION_SLICES >= 1 then counts
+//                         the linear segments between the knot states
 //                         (PT_ROTAT_UNITS 0 radians / 1 degrees: the unit of the scene's ROTAT values)
 //   PT_SHIM_BATCH (1)     iterations that may be pending inside the shim before they are rendered together
 //                         (only while nobody can observe them: no PBO, no read-back due); 1 = render every call
@@ -63,6 +65,7 @@ struct ShimState {
     int motion_slices = -1, motion_rotat = 0;      // -1: take PT_MOTION_SLICES / PT_ROTAT_UNITS at the first call
     bool motion_dirty = true;
     int motion_frame = -1;
+    int motion_per_ray = 0;                        // PT_MOTION_PER_RAY: PT_MOTION_SLICES then counts linear segments (>= 1)
 };
 ShimState g;
 
@@ -150,6 +153,8 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
         o.direct_light = env_int("PT_DIRECT_LIGHT", o.direct_light);
         o.absorption = env_int("PT_ABSORPTION", o.absorption);
         o.scatter = env_int("PT_SCATTER", o.scatter);
+        o.motion_per_ray = env_int("PT_MOTION_PER_RAY", o.motion_per_ray);
+        g.motion_per_ray = o.motion_per_ray;
         if (getenv("PT_LENS_RADIUS")) o.lens_radius = (float)atof(getenv("PT_LENS_RADIUS"));
         if (getenv("PT_FOCAL_DISTANCE")) o.focal_distance = (float)atof(getenv("PT_FOCAL_DISTANCE"));
         o.seed = (unsigned)env_int("PT_SEED", 0);
@@ -220,7 +225,7 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
     // motion blur: the shutter stays open until the next frame of the caller's arrays, when there is one
     if (scene_changed || g.motion_dirty || g.motion_frame != frame) {
         flush_pending();
-        if (g.motion_slices > 1 && frame + 1 < renderCam->frames) {
+        if ((g.motion_slices > 1 || (g.motion_per_ray && g.motion_slices >= 1)) && frame + 1 < renderCam->frames) {
             std::vector<pt_static_geom> next = list;
             for (int i = 0; i < numberOfGeoms; i++) {
                 memcpy(&next[(size_t)i].translation, &geoms[i].translations[frame + 1], sizeof next[0].translation);

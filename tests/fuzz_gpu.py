@@ -80,9 +80,24 @@ def main():
         ga = (O.StaticGeom * len(geoms))(*geoms)
         ma = (O.Material * len(mats))(*mats)
         cam = O.make_camera(W, H, eye, view, up, fovy)
+        motion = None
+        if meshes is None and not opts.get("direct_light") and not opts.get("scatter") and rng.random() < 0.15:
+            # motion blur with a shutter time per ray: a second frame (every object moved, turned and rescaled a little,
+            # sometimes the camera too), 1..5 linear segments; scalar geometry path
+            gb = [O.make_geom(g.type, g.materialid, np.array(g.translation.tup()) + rng.normal(0, 0.4, 3),
+                              np.array(g.rotation.tup()) + rng.normal(0, 0.3, 3), np.array(g.scale.tup()) * rng.uniform(0.8, 1.25, 3)) for g in geoms]
+            gba = (O.StaticGeom * len(gb))(*gb)
+            cam_b = O.make_camera(W, H, eye + rng.normal(0, 0.3, 3), view + rng.normal(0, 0.05, 3), up, fovy) if rng.random() < 0.5 else None
+            motion = (gba, cam_b, int(rng.integers(1, 6)))
+            gopts["geom_path"] = int(rng.choice([0, 1]))
+            strip = None if rng.random() < 0.5 else strip
         sh = []
-        ref, live = O.render(ga, len(geoms), ma, len(mats), cam, depth, iters=iters, shadow_out=sh, meshes=meshes, **opts)
-        if strip is None and rng.random() < 0.25 and H >= 4:
+        if motion:
+            kg, kc = O.motion_knots(ga, motion[0], len(geoms), cam, motion[1], motion[2])
+            ref, live = O.render(ga, len(geoms), ma, len(mats), cam, depth, iters=iters, shadow_out=sh, knot_geoms=kg, knot_cams=kc, **opts)
+        else:
+            ref, live = O.render(ga, len(geoms), ma, len(mats), cam, depth, iters=iters, shadow_out=sh, meshes=meshes, **opts)
+        if motion is None and strip is None and rng.random() < 0.25 and H >= 4:
             # the single-process multi-device handle (several contexts on device 0): bands or strips, host gather
             ndev = int(rng.integers(1, 5))
             srows = int(rng.choice([0, 1, 2, 8]))
@@ -130,6 +145,9 @@ def main():
                 if meshes:
                     r.set_meshes(meshes)
                 r.set_camera(pkg.CameraData.from_buffer_copy(cam))
+                if motion:
+                    r.set_options(motion_per_ray=1)
+                    r.set_motion(C.cast(motion[0], C.POINTER(pkg.StaticGeom)), motion[1], motion[2], pkg.ROTAT_RADIANS)
                 r.clear_image()
                 r.render(1, iters)
                 img = r.download_image()
@@ -146,7 +164,7 @@ def main():
                   [int(x) for x in st.live_in[:depth]] == [int(x) for x in live] and int(st.shadow_rays) == sh[0])
         if not ok:
             bad += 1
-            print(f"MISMATCH case {case}: prims={n_prims} {W}x{H} depth={depth} iters={iters} {opts} {gopts} strip={strip} "
+            print(f"MISMATCH case {case}: prims={n_prims} {W}x{H} depth={depth} iters={iters} {opts} {gopts} strip={strip} motion={motion[2] if motion else None} "
                   f"max|d|={np.abs(img - (want if strip else ref)).max():g}", flush=True)
         if (case - seed0) % 25 == 24:
             print(f"... {case - seed0 + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)

@@ -75,7 +75,8 @@ class OMesh(C.Structure):           # o_mesh
 
 class Extras(C.Structure):          # o_extras
     _fields_ = [("n_meshes", C.c_int), ("meshes", C.POINTER(OMesh)), ("n_slices", C.c_int),
-                ("slice_geoms", C.POINTER(StaticGeom)), ("slice_cams", C.POINTER(CameraData))]
+                ("slice_geoms", C.POINTER(StaticGeom)), ("slice_cams", C.POINTER(CameraData)),
+                ("n_knots", C.c_int), ("knot_geoms", C.POINTER(StaticGeom)), ("knot_cams", C.POINTER(CameraData))]
 
 
 class Scene(C.Structure):
@@ -152,6 +153,7 @@ def lib():
         "o_interpolateGeom": (StaticGeom, [P(StaticGeom), P(StaticGeom), f, i]),
         "o_interpolateCamera": (CameraData, [P(CameraData), P(CameraData), f]),
         "o_sliceTime": (f, [i, i]),
+        "o_knotTime": (f, [i, i]),
         "o_free_obj": (None, [P(f)]),
         "o_calculateScatterAndAbsorption": (i, [P(Ray), P(f), P(ScatterProps), P(Vec3), P(Material), f, f, f]),
         "o_trace_path": (Vec3, [P(StaticGeom), i, P(Material), i, P(CameraData), P(Options), i, i, u, P(i)]),
@@ -259,7 +261,7 @@ class LoadedScene:
         self.camera = c
 
 
-def make_extras(meshes=None, slice_geoms=None, slice_cams=None, nG=0):
+def make_extras(meshes=None, slice_geoms=None, slice_cams=None, nG=0, knot_geoms=None, knot_cams=None):
     """o_extras from {geom index: [n, 9] float32 array} and / or motion slices (a list of StaticGeom arrays of nG entries
     each, optionally a list of CameraData).  Returns (Extras, keep-alive list)."""
     ex, keep = Extras(), []
@@ -281,6 +283,17 @@ def make_extras(meshes=None, slice_geoms=None, slice_cams=None, nG=0):
             cams = (CameraData * len(slice_cams))(*slice_cams)
             ex.slice_cams = cams
             keep.append(cams)
+    if knot_geoms:                                  # per-ray motion blur: scene states at shutter times k / (n - 1)
+        flat = (StaticGeom * (len(knot_geoms) * nG))()
+        for k, sg in enumerate(knot_geoms):
+            for j in range(nG):
+                flat[k * nG + j] = sg[j]
+        ex.n_knots, ex.knot_geoms = len(knot_geoms), flat
+        keep.append(flat)
+        if knot_cams:
+            cams = (CameraData * len(knot_cams))(*knot_cams)
+            ex.knot_cams = cams
+            keep.append(cams)
     return ex, keep
 
 
@@ -299,9 +312,25 @@ def motion_slices(geoms_a, geoms_b, nG, cam_a, cam_b, slices, rotat_units=ROTAT_
     return sg, sc
 
 
+def motion_knots(geoms_a, geoms_b, nG, cam_a, cam_b, segments, rotat_units=ROTAT_RADIANS):
+    """The segments + 1 knot states of per-ray motion blur from frame a to frame b (shutter times k / segments):
+    (list of StaticGeom arrays, list of cameras or None), by the oracle's o_interpolateGeom / o_interpolateCamera."""
+    L = lib()
+    kg, kc = [], []
+    for k in range(segments + 1):
+        t = L.o_knotTime(k, segments + 1)
+        arr = (StaticGeom * max(1, nG))()
+        for j in range(nG):
+            arr[j] = L.o_interpolateGeom(C.byref(geoms_a[j]), C.byref(geoms_b[j]), t, rotat_units)
+        kg.append(arr)
+        if cam_b is not None:
+            kc.append(L.o_interpolateCamera(C.byref(cam_a), C.byref(cam_b), t))
+    return kg, (kc if cam_b is not None else None)
+
+
 def render(geoms, nG, mats, nM, cam, depth, iters=1, iter_first=1, rr_start=-1, seed=0, trig=TRIG_POLY,
            image=None, nthreads=None, direct_light=0, shadow_out=None, absorption=0, lens_radius=0.0, focal_distance=1.0,
-           scatter=0, meshes=None, slice_geoms=None, slice_cams=None):
+           scatter=0, meshes=None, slice_geoms=None, slice_cams=None, knot_geoms=None, knot_cams=None):
     """Returns (image[H,W,3] float32, live_in[depth] uint64); shadow_out (a list) receives the shadow-ray count."""
     W, H = int(cam.resolution.x), int(cam.resolution.y)
     if image is None:
@@ -313,7 +342,7 @@ def render(geoms, nG, mats, nM, cam, depth, iters=1, iter_first=1, rr_start=-1, 
     if nthreads is None:
         nthreads = os.cpu_count() or 1
     shadow = C.c_ulonglong(0)
-    ex, keep = make_extras(meshes, slice_geoms, slice_cams, nG)
+    ex, keep = make_extras(meshes, slice_geoms, slice_cams, nG, knot_geoms, knot_cams)
     rc = lib().o_render_ex(geoms, nG, mats, nM, C.byref(cam), C.byref(opt), C.byref(ex), image.ctypes.data, iter_first, iters,
                            live.ctypes.data, C.byref(shadow), nthreads)
     del keep

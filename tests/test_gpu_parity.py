@@ -1030,6 +1030,67 @@ def test_motion_blur_matches_oracle(pkg, slices, iters, extra):
     assert np.array_equal(static, c0) and not np.array_equal(g, c0)
 
 
+@pytest.mark.parametrize("segments,iters,extra", [(1, 20, {}), (4, 37, {"batch": 5, "rr_start": 2}), (7, 18, {"lens_radius": 0.3, "focal_distance": 9.0, "absorption": 1}),
+                                                  (2, 35, {"sequences": 1, "geom_path": 1})])
+def test_motion_blur_per_ray_matches_oracle(pkg, segments, iters, extra):
+    """pt_options.motion_per_ray: every path draws its shutter time (third number of its camera stream) and sees matrices
+    and camera vectors interpolated entry-wise between the two knots around it, at all of its bounces (FEAT_MOTION
+    kernels on the scalar path; the time is re-drawn from the stream at every bounce, nothing is stored in the ray)."""
+    path = os.path.join(SCENES, "sampleScene_anim.txt")
+    W, H, depth = 96, 72, 6
+    a, b = pkg.SceneFile(path, 1, frame=0), pkg.SceneFile(path, 1, frame=1)
+    a.set_resolution(W, H)
+    with pkg.Renderer(0) as r:
+        r.set_options(depth=depth, motion_per_ray=1, **extra)
+        r.set_scene(a.geoms, a.n_objects, a.mats, a.n_materials)
+        r.set_camera(a.camera)
+        r.set_motion(b.geoms, b.camera, segments, pkg.ROTAT_DEGREES)
+        r.clear_image()
+        r.render(1, 7)
+        r.render(8, iters - 7)
+        g = r.download_image()
+        st = r.stats()
+        r.set_motion(None, None, 0)                       # off again: the static frame
+        r.clear_image()
+        r.render(1, 3)
+        static = r.download_image()
+    oa, ob = O.LoadedScene(path, 1, frame=0), O.LoadedScene(path, 1, frame=1)
+    oa.set_resolution(W, H)
+    kg, kc = O.motion_knots(oa.geoms, ob.geoms, oa.n_objects, oa.camera, ob.camera, segments, O.ROTAT_DEGREES)
+    okw = {k: v for k, v in extra.items() if k in ("rr_start", "lens_radius", "focal_distance", "absorption")}
+    c, lc = O.render(oa.geoms, oa.n_objects, oa.mats, oa.n_materials, oa.camera, depth, iters=iters, knot_geoms=kg, knot_cams=kc, **okw)
+    check(g, c, [int(x) for x in st.live_in[:depth]], [int(x) for x in lc], f"per-ray motion blur, {segments} segment(s)")
+    assert int(st.iterations) == iters
+    c0, _ = O.render(oa.geoms, oa.n_objects, oa.mats, oa.n_materials, oa.camera, depth, iters=3, **okw)
+    assert np.array_equal(static, c0) and not np.array_equal(g, c0)
+
+
+def test_motion_blur_per_ray_camera_at_rest_and_errors(pkg):
+    path = os.path.join(SCENES, "sampleScene_anim.txt")
+    W, H, depth = 64, 48, 4
+    a, b = pkg.SceneFile(path, 1, frame=0), pkg.SceneFile(path, 1, frame=1)
+    a.set_resolution(W, H)
+    with pkg.Renderer(0) as r:
+        r.set_options(depth=depth, motion_per_ray=1)
+        r.set_scene(a.geoms, a.n_objects, a.mats, a.n_materials)
+        r.set_camera(a.camera)
+        r.set_motion(b.geoms, None, 3, pkg.ROTAT_DEGREES)      # the camera does not move
+        r.clear_image()
+        r.render(1, 5)
+        g = r.download_image()
+        st = r.stats()
+        for bad in (dict(direct_light=1), dict(scatter=1), dict(geom_path=5), dict(workgroup=512)):
+            r.set_options(**bad)
+            with pytest.raises(pkg.PtError):
+                r.clear_image()
+            r.set_options(**{k: 0 for k in bad})
+    oa, ob = O.LoadedScene(path, 1, frame=0), O.LoadedScene(path, 1, frame=1)
+    oa.set_resolution(W, H)
+    kg, _ = O.motion_knots(oa.geoms, ob.geoms, oa.n_objects, oa.camera, None, 3, O.ROTAT_DEGREES)
+    c, lc = O.render(oa.geoms, oa.n_objects, oa.mats, oa.n_materials, oa.camera, depth, iters=5, knot_geoms=kg)
+    check(g, c, [int(x) for x in st.live_in[:depth]], [int(x) for x in lc], "per-ray motion blur, camera at rest")
+
+
 # ---------------------------------------------------------------- committed golden fixtures
 def _golden_cases():
     import json
