@@ -150,11 +150,13 @@ __device__ __forceinline__ bool waveMissesBoxFromEye(const float *box_eye, int g
     const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
     return (__builtin_amdgcn_fcmpf(tn, tf, FCMP_OLE) & __ballot(valid)) == 0ull;
 }
+// finite reciprocal of a direction (culling only): |component| kept above 1e-20 with its sign -- v_max + v_bfi instead of
+// two compare / select pairs per component (a zero component takes the sign of its zero: either sign brackets the slab)
 __device__ __forceinline__ f3 approxInverse(f3 d)
 {
-    return mk(__builtin_amdgcn_rcpf(fabsf(d.x) > 1e-20f ? d.x : (d.x < 0 ? -1e-20f : 1e-20f)),
-              __builtin_amdgcn_rcpf(fabsf(d.y) > 1e-20f ? d.y : (d.y < 0 ? -1e-20f : 1e-20f)),
-              __builtin_amdgcn_rcpf(fabsf(d.z) > 1e-20f ? d.z : (d.z < 0 ? -1e-20f : 1e-20f)));
+    return mk(__builtin_amdgcn_rcpf(__builtin_copysignf(fmaxf(fabsf(d.x), 1e-20f), d.x)),
+              __builtin_amdgcn_rcpf(__builtin_copysignf(fmaxf(fabsf(d.y), 1e-20f), d.y)),
+              __builtin_amdgcn_rcpf(__builtin_copysignf(fmaxf(fabsf(d.z), 1e-20f), d.z)));
 }
 
 template <int GEOM, bool FIRST, class PR>

@@ -212,9 +212,12 @@ __device__ __forceinline__ void sincos_poly(float a, float &sn, float &cs)
     float s = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
     float c = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z
               - 0.5f * z + 1.0f;
-    int q = k & 3;
-    sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
-    cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+    // quadrant q = k & 3:  sin = s, c, -s, -c;  cos = c, -s, -c, s.  One select per output on the quadrant's low bit and the
+    // sign flipped through the bit pattern (a negation IS a flip of bit 31): 2 v_cndmask instead of 6 compare / select pairs
+    const uint32_t q = (uint32_t)k & 3u;
+    const bool odd = (q & 1u) != 0u;
+    sn = __uint_as_float(__float_as_uint(odd ? c : s) ^ ((q & 2u) << 30));
+    cs = __uint_as_float(__float_as_uint(odd ? s : c) ^ (((q + 1u) & 2u) << 30));
 }
 
 // multiplyMV (ref: src/intersections.h:53-59): rows 0..2 of a row-major 3x4 block dotted with (v, w)

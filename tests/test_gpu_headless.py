@@ -175,3 +175,27 @@ def test_headless_motion_blur(tmp_path):
         img, _ = O.render(a.geoms, a.n_objects, a.mats, a.n_materials, a.camera, depth, iters=iters, **kw)
         want = np.clip(img * np.float32(255.0), 0, 255).astype(np.uint8)[:, ::-1, :]
         assert np.array_equal(got, want), frame
+
+
+def test_headless_motion_blur_per_ray(tmp_path):
+    """PT_MOTION_PER_RAY=1 motion=2: the same walk through the frames with a shutter time per ray (two linear segments
+    between three knot states) through the reference-signature shim; each image == the oracle's."""
+    pkg = load_package()
+    W, H, depth, iters, K = 64, 48, 4, 20, 2
+    scene = os.path.join(ROOT, "scenes", "sampleScene_anim.txt")
+    env = dict(os.environ, PT_DEPTH=str(depth), PT_MOTION_PER_RAY="1")
+    res = subprocess.run([pkg.HEADLESS_PATH, f"scene={scene}", f"res={W}x{H}", f"iterations={iters}", "rotat=degrees", f"motion={K}",
+                          f"out={tmp_path}"], env=env, capture_output=True, text=True, timeout=180)
+    assert res.returncode == 0, res.stdout + res.stderr
+    for frame in range(3):
+        got = read_bmp(os.path.join(tmp_path, f"anim.{frame}.bmp"))
+        a = O.LoadedScene(scene, O.ROTAT_DEGREES, frame=frame)
+        a.set_resolution(W, H)
+        kw = {}
+        if frame < 2:
+            b = O.LoadedScene(scene, O.ROTAT_DEGREES, frame=frame + 1)
+            kg, kc = O.motion_knots(a.geoms, b.geoms, a.n_objects, a.camera, b.camera, K, O.ROTAT_DEGREES)
+            kw = dict(knot_geoms=kg, knot_cams=kc)
+        img, _ = O.render(a.geoms, a.n_objects, a.mats, a.n_materials, a.camera, depth, iters=iters, **kw)
+        want = np.clip(img * np.float32(255.0), 0, 255).astype(np.uint8)[:, ::-1, :]
+        assert np.array_equal(got, want), frame
