@@ -37,19 +37,20 @@ __device__ __forceinline__ f3 cross(f3 x, f3 y)
 // inputs/results, zero, inf and NaN.  Inside the usual range a v_sqrt_f32 / v_rcp_f32 seed plus the same
 // FMA corrections is already exactly rounded: checked against hipcc's results for ALL 2^32 inputs
 // (profiles/microbench/exact_math.hip, and pt_selftest_math() in every GPU test run):
-//   sqrt_core(x) == sqrtf(x)   for every x >= 2^-104, +inf and NaN      (used for x >= 2^-96)
+//   sqrt_core(x) == sqrtf(x)   for every 2^-96 <= x < +inf
 //   rcp_core(x)  == 1.0f / x   for every normal |x| < 2^126
 // Outside those ranges the wave falls back to the compiler's expansion.  The range test is made
 // wave-uniform with a ballot, so it costs one scalar branch and both sides stay straight-line code.
 // ---------------------------------------------------------------------------------------------
+// (round 3: v_rsq seed + one step on the product form, fma only -- round 2's v_sqrt seed was corrected by two compare /
+// select pairs on exact residuals, and v_cmp / v_cndmask issue at 4 cycles against 2.5 for an fma: 19 instead of 35 cycles.
+// Exhaustive check of the candidates: profiles/microbench/exact_sqrt2.hip, profiles/r03/exact_sqrt2.txt.)
 __device__ __forceinline__ float sqrt_core(float x)
 {
-    float y = __builtin_amdgcn_sqrtf(x);                               // <= 1 ulp
-    const float ym = __uint_as_float(__float_as_uint(y) - 1u), yp = __uint_as_float(__float_as_uint(y) + 1u);
-    const float rm = __builtin_fmaf(-ym, y, x), rp = __builtin_fmaf(-yp, y, x);   // exact residuals
-    y = (rm <= 0.0f) ? ym : y;
-    y = (rp > 0.0f) ? yp : y;
-    return y;
+    const float s = __builtin_amdgcn_rsqf(x);                          // <= 1 ulp
+    const float g = x * s, h = 0.5f * s;
+    const float r = __builtin_fmaf(-g, g, x);                         // exact residual of the estimate g
+    return __builtin_fmaf(r, h, g);
 }
 __device__ __forceinline__ float rcp_core(float d)
 {
@@ -64,8 +65,8 @@ __device__ __forceinline__ float rcp_core(float d)
 enum { FCMP_OGE = 3, FCMP_OLE = 5, FCMP_UGE = 11, FCMP_ULT = 12, ICMP_UGE = 35 };     // llvm::CmpInst predicates
 __device__ __forceinline__ float sqrt_rn(float x)                      // == sqrtf(x) for every x
 {
-    // outside the range: tiny, zero, negative, NaN ("unordered or less than")
-    if (__builtin_amdgcn_fcmpf(x, 0x1p-96f, FCMP_ULT) == 0ull) return sqrt_core(x);
+    // 2^-96 <= x < +inf as one unsigned compare on the bit pattern: tiny, zero, negative numbers, +inf and NaN fail it
+    if (__builtin_amdgcn_uicmp(__float_as_uint(x) - 0x0F800000u, 0x7F800000u - 0x0F800000u, ICMP_UGE) == 0ull) return sqrt_core(x);
     return sqrtf(x);
 }
 __device__ __forceinline__ float rcp_rn(float x)                       // == 1.0f / x for every x
@@ -171,10 +172,15 @@ __host__ __device__ __forceinline__ uint32_t stream_key(uint32_t iteration, uint
 }
 __device__ __forceinline__ uint32_t minstd_seed(uint32_t s)
 {
-    const uint32_t m = 2147483647u;            // s % m for s < 2^32 needs at most two subtractions
-    if (s >= m) s -= m;
-    if (s >= m) s -= m;
-    return s == 0u ? 1u : s;
+    // s % m for s < 2^32 = 2m + 2 needs at most two subtractions; each is "the smaller of s and s - m as unsigned" (s < m:
+    // s - m wraps around to the top of the range; s >= m: s - m < s) -- v_sub + v_min instead of compare / select / subtract;
+    // 0 -> 1 is a v_max.  Same value for every s (integer identity, checked for all 2^32 seeds by pt_selftest_math).
+    const uint32_t m = 2147483647u;
+    uint32_t w = s - m;
+    s = w < s ? w : s;
+    w = s - m;
+    s = w < s ? w : s;
+    return s > 1u ? s : 1u;
 }
 __device__ __forceinline__ uint32_t minstd_next(uint32_t x)
 {

@@ -42,6 +42,9 @@ __global__ __launch_bounds__(256) void k_selftest_math(unsigned long long *out)
         const float e = 1.0f / sqrtf(x), f = rsqrt_rn(x), g = rsqrt_near_one(x);
         if (__float_as_uint(e) != __float_as_uint(f) && !(e != e && f != f)) bad2++;
         if (__float_as_uint(e) != __float_as_uint(g) && !(e != e && g != g)) bad2++;
+        // minstd_seed's branch-free form against the definition: s mod (2^31 - 1), 0 -> 1 (counted with the 1/sqrt checks)
+        const uint32_t sd = (uint32_t)i, md = sd % 2147483647u;
+        if (minstd_seed(sd) != (md == 0u ? 1u : md)) bad2++;
     }
     if (bad0) atomicAdd(&out[0], bad0);
     if (bad1) atomicAdd(&out[1], bad1);
