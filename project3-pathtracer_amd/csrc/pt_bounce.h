@@ -40,6 +40,8 @@ static constexpr uint32_t SLOT_SHIFT = 27;        // pixel word = tile-local pix
 static constexpr uint32_t PIX_MASK = (1u << SLOT_SHIFT) - 1u;
 
 typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
+typedef float v4f __attribute__((ext_vector_type(4)));      // operand types of the non-temporal load / store builtins
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 // diagnostic builds (-DPT_DEBUG_BOUNDS=1, PT_DEBUG_BOUNDS=1 at run time prints it): report the first out-of-range index
 // (code, value, limit) in IterState::dbg and let the caller make the access harmless
@@ -1196,6 +1198,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
 
     IterState *st = p.st;
     const uint32_t iter = st->iter;
+    const uint32_t serial = st->serial;                // stamp of this batch's radiance-plane entries
     unsigned long long clk0 = 0, rt0 = 0;
     if (bounce == 1 && blockIdx.x == 0 && tid == 0) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     const unsigned long long span0 = (DEBUG_SPAN && bounce == 1 && tid == 0) ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -1255,6 +1258,52 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
     Cursor cur = {0u, 0u, (uint32_t)__builtin_amdgcn_readfirstlane((int)s_segn[0])};
     for (uint32_t R = blockIdx.x; R * NW < total_chunks; R += gridDim.x, ++round) {     // workgroup-uniform trip count
         const unsigned long long tc0 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
+#if defined(PT_KO)
+        // sensitivity experiments (profiles/r03/knockout.txt; never in the product build): extra work that changes no result,
+        // once per 64-ray round of the later bounces -- which resource does the kernel's speed follow?
+        if (!FIRST) {
+#if PT_KO == 1      // PT_KO_N dependent v_fma_f32 (VALU issue)
+            float ko = (float)lane;
+#pragma unroll
+            for (int k = 0; k < PT_KO_N; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(ko));
+            if (ko == 12345.678f) st->dbg[7] = 1ull;
+#elif PT_KO == 2    // PT_KO_N wave-wide ds_read_b128 of one address (LDS pipe, no bank conflicts)
+            float4 ko = make_float4(0, 0, 0, 0);
+            const uint32_t ko_addr = (uint32_t)(uintptr_t)smem;
+#pragma unroll
+            for (int k = 0; k < PT_KO_N; ++k) { float4 t4; asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(t4) : "v"(ko_addr) : "memory"); ko.x += t4.x; }
+            if (ko.x == 12345.678f) st->dbg[7] = 1ull;
+#elif PT_KO == 3    // PT_KO_N x 64 cycles of sleep (pure latency: the wave issues nothing)
+#pragma unroll
+            for (int k = 0; k < PT_KO_N; ++k) __builtin_amdgcn_s_sleep(1);
+#elif PT_KO == 4    // PT_KO_N dependent s_add_u32 (scalar issue)
+            uint32_t ko = (uint32_t)wave;
+#pragma unroll
+            for (int k = 0; k < PT_KO_N; ++k) asm volatile("s_add_u32 %0, %0, 1" : "+s"(ko));
+            if (ko == 0x12345678u) st->dbg[7] = 1ull;
+#elif PT_KO == 6    // the chunk's ray records read PT_KO_N more times from the OTHER pool (same bytes, other addresses: HBM / L2 traffic)
+            {
+                Cursor kc = cur;
+                uint32_t ki;
+                float acc = 0.0f;
+                if (locate(kc, R, ki)) {
+#pragma unroll
+                    for (int k = 0; k < PT_KO_N; ++k) {
+                        const float4 a4 = out.a[ki + 64u * (uint32_t)k];
+                        const float4 b4 = out.b[ki + 64u * (uint32_t)k];
+                        acc += a4.x + b4.y;
+                    }
+                }
+                if (acc == 12345.678f) st->dbg[7] = 1ull;
+            }
+#elif PT_KO == 5    // PT_KO_N v_cndmask (4-cycle class)
+            float ko = (float)lane;
+#pragma unroll
+            for (int k = 0; k < PT_KO_N; ++k) asm volatile("v_cndmask_b32 %0, %0, %0, vcc" : "+v"(ko));
+            if (ko == 12345.678f) st->dbg[7] = 1ull;
+#endif
+        }
+#endif
         uint32_t i;
         bool valid = locate(cur, R, i);
         const bool in_pool = valid;                               // the slot exists (COMPACT 0: it may hold a dead ray)
@@ -1336,12 +1385,14 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
         } else {
             if (valid && !dbgInRange(p, 1, i, (unsigned long long)p.segcap * (unsigned long long)p.nshard)) valid = false;
             if (valid) {
-                const float2 c = in.c[i];
+                const v2f c_ = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(&in.c[i]));
+                const float2 c = make_float2(c_.x, c_.y);
                 pix = __float_as_uint(c.y);
                 if (COMPACT == 0 && pix == DEAD) valid = false;
                 if (valid) {
-                    const float4 a = in.a[i];
-                    const float4 b = in.b[i];
+                    const v4f a_ = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(&in.a[i]));
+                    const v4f b_ = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(&in.b[i]));
+                    const float4 a = make_float4(a_.x, a_.y, a_.z, a_.w), b = make_float4(b_.x, b_.y, b_.z, b_.w);
                     o = mk(a.x, a.y, a.z);
                     d = mk(a.w, b.x, b.y);
                     T = mk(b.z, b.w, c.x);
@@ -1589,28 +1640,26 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                     if (fabsf(hs.t - ldist) <= tol) L = L + Ld;          // the sampled point itself is what the ray reached
                 }
             }
-            if (valid) {
-                // the plane entry accumulates along the path: set at bounce 0, added to afterwards (exclusive owner)
-                float *lp = p.lbuf + 3u * ((size_t)((pix >> SLOT_SHIFT) & (uint32_t)(MAXSLOT - 1)) * npix + (size_t)(pix & PIX_MASK));
-                if (!dbgInRange(p, 6, (unsigned long long)((pix >> SLOT_SHIFT) & (uint32_t)(MAXSLOT - 1)) * npix + (pix & PIX_MASK), (unsigned long long)npix * st->nslot)) lp = p.lbuf;
-                if (FIRST) {
-                    lp[0] = L.x;
-                    lp[1] = L.y;
-                    lp[2] = L.z;
-                } else if (L.x != 0.0f || L.y != 0.0f || L.z != 0.0f) {
-                    lp[0] = lp[0] + L.x;
-                    lp[1] = lp[1] + L.y;
-                    lp[2] = lp[2] + L.z;
-                }
+            if (valid && (L.x != 0.0f || L.y != 0.0f || L.z != 0.0f)) {
+                // the plane entry accumulates along the path (exclusive owner); an entry of another batch counts as zero
+                float4 *lp = reinterpret_cast<float4 *>(p.lbuf) + ((size_t)((pix >> SLOT_SHIFT) & (uint32_t)(MAXSLOT - 1)) * npix + (size_t)(pix & PIX_MASK));
+                if (!dbgInRange(p, 6, (unsigned long long)((pix >> SLOT_SHIFT) & (uint32_t)(MAXSLOT - 1)) * npix + (pix & PIX_MASK), (unsigned long long)npix * st->nslot)) lp = reinterpret_cast<float4 *>(p.lbuf);
+                float4 e = *lp;
+                if (__float_as_uint(e.w) != serial) e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                *lp = make_float4(e.x + L.x, e.y + L.y, e.z + L.z, __uint_as_float(serial));
             }
-        } else if (valid && !alive) {
-            // the path ends here: its radiance sample goes to this iteration slot's plane; k_accumulate folds
-            // the planes into the running mean in iteration order once the launch sequence is done
-            float *lp = p.lbuf + 3u * ((size_t)(pix >> SLOT_SHIFT) * npix + (size_t)(pix & PIX_MASK));
-            if (!dbgInRange(p, 7, (unsigned long long)(pix >> SLOT_SHIFT) * npix + (pix & PIX_MASK), (unsigned long long)npix * st->nslot)) lp = p.lbuf;
-            lp[0] = L.x;
-            lp[1] = L.y;
-            lp[2] = L.z;
+        } else if (valid && !alive && (L.x != 0.0f || L.y != 0.0f || L.z != 0.0f)) {
+            // The path ends here with a non-zero radiance sample: it goes to its iteration slot's plane, stamped with the batch's
+            // serial number; k_accumulate folds the planes into the running mean in iteration order once the launch sequence is
+            // done and takes every entry that does not carry this batch's serial for zero.  (Nineteen of twenty paths of the
+            // benchmark scenes end with a zero sample -- they leave the scene or run out of bounces -- and round 3's sensitivity
+            // runs priced the unconditional 12-byte store at 7-10 % of the kernel: profiles/r03/knockout.txt.)
+            float4 *lp = reinterpret_cast<float4 *>(p.lbuf) + ((size_t)(pix >> SLOT_SHIFT) * npix + (size_t)(pix & PIX_MASK));
+            if (!dbgInRange(p, 7, (unsigned long long)(pix >> SLOT_SHIFT) * npix + (pix & PIX_MASK), (unsigned long long)npix * st->nslot)) lp = reinterpret_cast<float4 *>(p.lbuf);
+#if defined(PT_KO) && PT_KO == 7      // (sensitivity experiment: the path's radiance sample is not written -- wrong image, same control flow)
+            if (L.x == 12345.678f)
+#endif
+            __builtin_nontemporal_store((v4f){L.x, L.y, L.z, __uint_as_float(serial)}, reinterpret_cast<v4f *>(lp));
         }
 
         const unsigned long long c3 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -1650,9 +1699,10 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
             if (alive && !dbgInRange(p, 4, dst, (unsigned long long)p.segcap * (unsigned long long)p.nshard)) alive = false;
             if (alive && !dbgInRange(p, 5, dst - out_base, p.segcap)) alive = false;
             if (alive) {
-                out.a[dst] = make_float4(o.x, o.y, o.z, d.x);
-                out.b[dst] = make_float4(d.y, d.z, T.x, T.y);
-                out.c[dst] = make_float2(T.z, __uint_as_float(pix));
+                // (the pools are written once and read once, a launch later and gigabytes apart: streaming stores / loads)
+                __builtin_nontemporal_store((v4f){o.x, o.y, o.z, d.x}, reinterpret_cast<v4f *>(&out.a[dst]));
+                __builtin_nontemporal_store((v4f){d.y, d.z, T.x, T.y}, reinterpret_cast<v4f *>(&out.b[dst]));
+                __builtin_nontemporal_store((v2f){T.z, __uint_as_float(pix)}, reinterpret_cast<v2f *>(&out.c[dst]));
             }
         } else {
             // no compaction (validation / ablation mode): the ray keeps slot i, dead slots are tagged

@@ -938,12 +938,15 @@ int configure(pt_ctx *c)
         nseq = atoi(getenv("PT_SEQUENCES"));
     c->nseq = nseq;
     // per-iteration radiance planes (one write per path, folded into the image by k_accumulate), per sequence
-    const size_t lbuf_bytes = ((size_t)nrays * 3 * sizeof(float) + 255) & ~(size_t)255;
+    // (16-byte entries: r, g, b and the serial number of the batch that wrote them; zeroed once -- no batch has serial 0)
+    const size_t lbuf_bytes = ((size_t)nrays * 4 * sizeof(float) + 255) & ~(size_t)255;
     if (c->lbuf_cap < lbuf_bytes * (size_t)nseq) {
         if (c->d_lbuf) (void)hipFree(c->d_lbuf);
         c->d_lbuf = nullptr; c->lbuf_cap = 0;
         HIP_TRY(hipMalloc((void **)&c->d_lbuf, lbuf_bytes * (size_t)nseq));
         c->lbuf_cap = lbuf_bytes * (size_t)nseq;
+        HIP_TRY(hipMemsetAsync(c->d_lbuf, 0, lbuf_bytes * (size_t)nseq, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
     }
     k.lbuf = c->d_lbuf;
 
@@ -1147,10 +1150,7 @@ int configure(pt_ctx *c)
         ks.st = c->d_state + sq;
     }
     k = c->kps[0];
-    if (getenv("PT_PRETOUCH")) {                     // experiment: write every pool / plane byte once before the first launch
-        HIP_TRY(hipMemsetAsync(c->d_pool, 0, 2 * one * (size_t)nseq, c->stream));
-        HIP_TRY(hipMemsetAsync(c->d_lbuf, 0, lbuf_bytes * (size_t)nseq, c->stream));
-    }
+    if (getenv("PT_PRETOUCH")) HIP_TRY(hipMemsetAsync(c->d_pool, 0, 2 * one * (size_t)nseq, c->stream));   // experiment: first touch of the pools
     if (getenv("PT_DEBUG_CLOCK")) fprintf(stderr, "[ptamd] launch sequences in flight: %d\n", nseq);
 
     c->dirty = false;
@@ -1318,6 +1318,13 @@ int pt_create(int device, pt_ctx **out)
         pt_destroy(c);
         return fail(PT_ERR_OOM, "cannot allocate iteration state");
     }
+    // batch serial numbers (the stamps of the radiance-plane entries): sequence q counts q + 4, q + 8, ... -- never zero, never
+    // another sequence's, never one of its own again, so no entry an earlier batch left anywhere in the planes is ever mistaken
+    for (uint32_t q = 1; q < (uint32_t)PT_MAX_SEQUENCES; ++q)
+        if (hipMemcpy(&c->d_state[q].serial, &q, sizeof q, hipMemcpyHostToDevice) != hipSuccess) {
+            pt_destroy(c);
+            return fail(PT_ERR_HIP, "cannot initialise the iteration state");
+        }
     *out = c;
     return PT_OK;
 }
@@ -1846,7 +1853,9 @@ int pt_reset_stats(pt_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     int rc = fold_timers(c);
     if (rc != PT_OK) return rc;
-    HIP_TRY(hipMemset(c->d_state, 0, PT_MAX_SEQUENCES * sizeof(pt::IterState)));
+    // (everything behind the header: the header holds the batch serial number, which outlives the statistics)
+    for (int sq = 0; sq < PT_MAX_SEQUENCES; ++sq)
+        HIP_TRY(hipMemset((unsigned char *)(c->d_state + sq) + offsetof(pt::IterState, counts), 0, sizeof(pt::IterState) - offsetof(pt::IterState, counts)));
     c->gpu_ms = 0.0;
     c->bounce_launches = 0;
     for (pt_ctx *ch : c->slice_ctx) { rc = pt_reset_stats(ch); if (rc != PT_OK) return rc; }

@@ -39,7 +39,11 @@ struct IterState {
     // Launch sequences in flight (pt_options.sequences): every sequence has an IterState of its own and takes every
     // sched_stride-th batch of the call, starting with its own number; a batch's first iteration follows from its index
     uint32_t sched_first, sched_stride;          // first iteration of the pt_render call; batches between two of this sequence's
-    uint32_t pad[25];
+    // Serial number of the running batch of this sequence (k_iter_begin counts it up; never reset while the radiance planes
+    // live): a radiance-plane entry carries the serial of the batch that wrote it, so only NON-ZERO samples are ever written
+    // (nineteen of twenty paths end with a zero sample) and nothing has to be cleared between batches
+    uint32_t serial;
+    uint32_t pad[24];
     uint32_t counts[(PT_MAX_DEPTH + 1) * NSHARD * CNT_STRIDE];   // live rays entering bounce b, per segment
     unsigned long long live_in[PT_MAX_DEPTH];    // summed over segments and iterations (stats)
     unsigned long long iterations;
@@ -88,7 +92,7 @@ struct KParams {
     float *image;          // tile framebuffer, fp32 RGB packed (12 B/pixel)
     int cull;              // 1 = skip primitives whose bounding sphere no lane of the wave can hit (large scenes)
     int nslot;             // most iterations in flight per launch sequence (1..PT_MAX_BATCH); a batch's own count is IterState::nslot
-    float *lbuf;           // nslot planes of npix fp32 RGB radiance samples, folded into `image` by k_accumulate
+    float *lbuf;           // nslot planes of npix entries (r, g, b, serial of the batch that wrote them: 16 B), folded into `image` by k_accumulate
     int nshard;            // pool segments in use: NSHARD (compaction 1), 1 otherwise
     uint32_t segcap;       // slots per pool segment
     IterState *st;

@@ -176,6 +176,7 @@ __global__ void k_iter_begin(IterState *st, uint32_t npix, int depth, int compac
         if (b < depth) st->live_in[b] += sum;
     }
     if (b == 0) {
+        st->serial += (uint32_t)PT_MAX_SEQUENCES;     // (stays congruent to the sequence's number: pt_create)
         st->iter = iter;
         st->nslot = nslot;
         st->sched_j = j + st->sched_stride;
@@ -184,55 +185,39 @@ __global__ void k_iter_begin(IterState *st, uint32_t npix, int depth, int compac
 }
 
 // Accumulation (DESIGN.md "Canonical semantics" 6): image = (image*(i-1) + L_i)/i for the batch's iterations in
-// order, one thread per pixel, streaming (the per-path samples were written to lbuf by k_bounce).
-__global__ __launch_bounds__(256) void k_accumulate(float *image, const float *lbuf, const IterState *st, int npix)
+// order, one thread per pixel, streaming.  The per-path samples were written to lbuf by k_bounce -- the non-zero ones
+// only, stamped with the batch's serial number: an entry with another stamp is a sample of zero.  All of a thread's plane
+// loads (16 bytes each, coalesced) are in flight before the dependent chain of divisions starts.
+__global__ __launch_bounds__(256) void k_accumulate(float *image, const float4 *lbuf, const IterState *st, int npix)
 {
-    const uint32_t iter0 = st->iter;
+    const uint32_t iter0 = st->iter, serial = st->serial;
     const int nslot = (int)st->nslot;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
         float r = image[3 * i], g = image[3 * i + 1], b = image[3 * i + 2];
-        for (int k = 0; k < nslot; ++k) {
-            const float *lp = lbuf + 3 * ((size_t)k * (size_t)npix + (size_t)i);
-            const uint32_t it = iter0 + (uint32_t)k;
-            const float fi = (float)it, fim1 = (float)(it - 1u);
-            // iteration 1 restarts the running mean: (old*0 + L)/1 == L for every finite old value, and taking L
-            // directly keeps a NaN / Inf left in a caller-owned buffer from surviving the restart
-            r = (it == 1u) ? lp[0] : (r * fim1 + lp[0]) / fi;
-            g = (it == 1u) ? lp[1] : (g * fim1 + lp[1]) / fi;
-            b = (it == 1u) ? lp[2] : (b * fim1 + lp[2]) / fi;
+        float4 L[PT_MAX_BATCH];
+#pragma unroll
+        for (int k = 0; k < PT_MAX_BATCH; ++k)
+            if (k < nslot) {
+                const v4f e = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(lbuf + (size_t)k * (size_t)npix + (size_t)i));
+                L[k] = make_float4(e.x, e.y, e.z, e.w);
+            }
+#pragma unroll
+        for (int k = 0; k < PT_MAX_BATCH; ++k) {
+            if (k < nslot) {
+                const bool have = __float_as_uint(L[k].w) == serial;
+                const float lr = have ? L[k].x : 0.0f, lg = have ? L[k].y : 0.0f, lb = have ? L[k].z : 0.0f;
+                const uint32_t it = iter0 + (uint32_t)k;
+                const float fi = (float)it, fim1 = (float)(it - 1u);
+                // iteration 1 restarts the running mean: (old*0 + L)/1 == L for every finite old value, and taking L
+                // directly keeps a NaN / Inf left in a caller-owned buffer from surviving the restart
+                r = (it == 1u) ? lr : (r * fim1 + lr) / fi;
+                g = (it == 1u) ? lg : (g * fim1 + lg) / fi;
+                b = (it == 1u) ? lb : (b * fim1 + lb) / fi;
+            }
         }
         image[3 * i] = r;
         image[3 * i + 1] = g;
         image[3 * i + 2] = b;
-    }
-}
-
-// The same on four consecutive floats per thread: the update does not care which channel a float is, so the image and
-// every radiance plane are flat arrays of 3*npix floats read as float4 (one 16-byte load per plane, all of a thread's
-// loads in flight before the dependent chain of divisions starts).  n4 = 3*npix/4 (the host checks divisibility and the
-// 16-byte alignment of both buffers, else the scalar kernel above runs).
-__global__ __launch_bounds__(256) void k_accumulate4(float4 *image, const float4 *lbuf, const IterState *st, int n4)
-{
-    const uint32_t iter0 = st->iter;
-    const int nslot = (int)st->nslot;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
-        float4 a = image[i];
-        float4 L[PT_MAX_BATCH];
-#pragma unroll
-        for (int k = 0; k < PT_MAX_BATCH; ++k)
-            if (k < nslot) L[k] = lbuf[(size_t)k * (size_t)n4 + (size_t)i];
-#pragma unroll
-        for (int k = 0; k < PT_MAX_BATCH; ++k) {
-            if (k < nslot) {
-                const uint32_t it = iter0 + (uint32_t)k;
-                const float fi = (float)it, fim1 = (float)(it - 1u);
-                a.x = (it == 1u) ? L[k].x : (a.x * fim1 + L[k].x) / fi;
-                a.y = (it == 1u) ? L[k].y : (a.y * fim1 + L[k].y) / fi;
-                a.z = (it == 1u) ? L[k].z : (a.z * fim1 + L[k].z) / fi;
-                a.w = (it == 1u) ? L[k].w : (a.w * fim1 + L[k].w) / fi;
-            }
-        }
-        image[i] = a;
     }
 }
 
@@ -353,16 +338,10 @@ hipError_t launch_iter_begin(hipStream_t s, IterState *st, int npix, int depth, 
 
 hipError_t launch_accumulate(hipStream_t s, float *image, const float *lbuf, const IterState *st, int npix)
 {
-    const bool vec = (3ll * npix) % 4 == 0 && ((uintptr_t)image | (uintptr_t)lbuf) % 16 == 0;
-    const int n = vec ? (int)(3ll * npix / 4) : npix;
-    int grid = (n + 255) / 256;
-    if (grid > 8192) grid = 8192;
+    int grid = (npix + 255) / 256;
+    if (grid > 16384) grid = 16384;
     if (grid < 1) grid = 1;
-    if (vec)
-        hipLaunchKernelGGL(k_accumulate4, dim3(grid), dim3(256), 0, s, reinterpret_cast<float4 *>(image),
-                           reinterpret_cast<const float4 *>(lbuf), st, n);
-    else
-        hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(256), 0, s, image, lbuf, st, npix);
+    hipLaunchKernelGGL(k_accumulate, dim3(grid), dim3(256), 0, s, image, reinterpret_cast<const float4 *>(lbuf), st, npix);
     return hipGetLastError();
 }
 
