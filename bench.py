@@ -359,7 +359,7 @@ def main():
         lib_batch = args.batch or 16
         nb_timed = (args.steps + lib_batch - 1) // lib_batch
         timed_batches = [args.steps // nb_timed + (1 if j < args.steps % nb_timed else 0) for j in range(nb_timed)]
-        launches_timed = nb_timed * args.depth       # one launch carries one bounce of one batch
+        launches_timed = int(st.bounce_launches)      # one launch carries one bounce of one batch (the camera kernel: bounces 0 and 1)
         region_ms = float(st.gpu_ms)
         achieved = alg_bytes / (region_ms * 1e-3) / 1e9
         prof_steps = timed_batches[0]          # one batch of the timed region's size: the same launch shape
