@@ -163,6 +163,16 @@ def test_launch_sequences_in_flight_are_invisible(pkg, batch, iters):
     assert sa.iterations == sb.iterations == iters
 
 
+def test_launch_sequences_many_small_batches(pkg):
+    """96 one-iteration batches alternate between the two sequences: 95 cross-stream hand-overs of the framebuffer (each
+    accumulate waits for the other stream's previous one).  Same bits as one sequence and as the oracle."""
+    a, la, _ = gpu_render(pkg, "sampleScene_spec.txt", 320, 200, 4, iters=96, batch=1, sequences=1)
+    b, lb, _ = gpu_render(pkg, "sampleScene_spec.txt", 320, 200, 4, iters=96, batch=1, sequences=2)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and la == lb
+    c, lc = cpu_render("sampleScene_spec.txt", 320, 200, 4, iters=96)
+    check(b, c, lb, lc, "96 one-iteration batches on two sequences")
+
+
 def test_launch_sequences_across_calls_and_features(pkg):
     """Two sequences in flight over several pt_render calls (resume), with direct lighting (planes accumulate along the
     path) and on the batched walk: same bits as the oracle."""
