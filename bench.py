@@ -451,8 +451,8 @@ def main():
                         "sum_b(live_in+live_out)*40 + P*24 per iteration) / HIP-event time of the timed region on the render "
                         "stream; avg_launch_ms = that time / launches: two launch sequences overlap, so a launch's own "
                         "duration in a rocprofv3 kernel trace is longer than this -- profiles/trace_union.py turns a trace "
-                        "into the same figure (union of the k_bounce intervals / launches).  The path is VALU-issue-bound, "
-                        "see DESIGN.md 5.3",
+                        "into the same figure (union of the k_bounce intervals / launches).  No single resource binds the "
+                        "kernel (sensitivity runs, profiles/r03/knockout.txt): see DESIGN.md 5.3",
             },
         }
         if value_pipelined is not None:
