@@ -1,5 +1,5 @@
 O=gpurun_out/${1:-r03m}
-LIBS="lib lib_ko6_1 lib_ko6_2 lib_ko7_0"
+LIBS="lib lib_ko1_200 lib_ko5_100 lib_ko2_50 lib_ko3_32 lib_ko4_200"
 mkdir -p $O
 for s in 2 1; do for i in 1 2; do for l in $LIBS; do
   PT_LIBPTAMD=$GRAFT_REPO_ROOT/project3-pathtracer_amd/$l/libptamd.so python bench.py --no-cpu-baseline --sequences $s > $O/${l}_s${s}_$i.json 2>>$O/err.txt

@@ -42,6 +42,23 @@ static constexpr uint32_t PIX_MASK = (1u << SLOT_SHIFT) - 1u;
 typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
 typedef float v4f __attribute__((ext_vector_type(4)));      // operand types of the non-temporal load / store builtins
 typedef float v2f __attribute__((ext_vector_type(2)));
+// streaming (`nt`) loads / stores of data that is written once and read once (-DPT_NO_NT: plain ones, for A/B runs)
+template <class V> __device__ __forceinline__ void nt_store(V v, V *p)
+{
+#if defined(PT_NO_NT)
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
+template <class V> __device__ __forceinline__ V nt_load(const V *p)
+{
+#if defined(PT_NO_NT)
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
 
 // diagnostic builds (-DPT_DEBUG_BOUNDS=1, PT_DEBUG_BOUNDS=1 at run time prints it): report the first out-of-range index
 // (code, value, limit) in IterState::dbg and let the caller make the access harmless
@@ -1385,13 +1402,13 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
         } else {
             if (valid && !dbgInRange(p, 1, i, (unsigned long long)p.segcap * (unsigned long long)p.nshard)) valid = false;
             if (valid) {
-                const v2f c_ = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(&in.c[i]));
+                const v2f c_ = nt_load(reinterpret_cast<const v2f *>(&in.c[i]));
                 const float2 c = make_float2(c_.x, c_.y);
                 pix = __float_as_uint(c.y);
                 if (COMPACT == 0 && pix == DEAD) valid = false;
                 if (valid) {
-                    const v4f a_ = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(&in.a[i]));
-                    const v4f b_ = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(&in.b[i]));
+                    const v4f a_ = nt_load(reinterpret_cast<const v4f *>(&in.a[i]));
+                    const v4f b_ = nt_load(reinterpret_cast<const v4f *>(&in.b[i]));
                     const float4 a = make_float4(a_.x, a_.y, a_.z, a_.w), b = make_float4(b_.x, b_.y, b_.z, b_.w);
                     o = mk(a.x, a.y, a.z);
                     d = mk(a.w, b.x, b.y);
@@ -1659,7 +1676,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
 #if defined(PT_KO) && PT_KO == 7      // (sensitivity experiment: the path's radiance sample is not written -- wrong image, same control flow)
             if (L.x == 12345.678f)
 #endif
-            __builtin_nontemporal_store((v4f){L.x, L.y, L.z, __uint_as_float(serial)}, reinterpret_cast<v4f *>(lp));
+            nt_store((v4f){L.x, L.y, L.z, __uint_as_float(serial)}, reinterpret_cast<v4f *>(lp));
         }
 
         const unsigned long long c3 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -1700,9 +1717,9 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
             if (alive && !dbgInRange(p, 5, dst - out_base, p.segcap)) alive = false;
             if (alive) {
                 // (the pools are written once and read once, a launch later and gigabytes apart: streaming stores / loads)
-                __builtin_nontemporal_store((v4f){o.x, o.y, o.z, d.x}, reinterpret_cast<v4f *>(&out.a[dst]));
-                __builtin_nontemporal_store((v4f){d.y, d.z, T.x, T.y}, reinterpret_cast<v4f *>(&out.b[dst]));
-                __builtin_nontemporal_store((v2f){T.z, __uint_as_float(pix)}, reinterpret_cast<v2f *>(&out.c[dst]));
+                nt_store((v4f){o.x, o.y, o.z, d.x}, reinterpret_cast<v4f *>(&out.a[dst]));
+                nt_store((v4f){d.y, d.z, T.x, T.y}, reinterpret_cast<v4f *>(&out.b[dst]));
+                nt_store((v2f){T.z, __uint_as_float(pix)}, reinterpret_cast<v2f *>(&out.c[dst]));
             }
         } else {
             // no compaction (validation / ablation mode): the ray keeps slot i, dead slots are tagged
