@@ -112,6 +112,7 @@ struct pt_ctx {
     size_t pool_cap = 0;
     float *d_lbuf = nullptr;    // per-iteration radiance planes of the running batch
     size_t lbuf_cap = 0;
+    unsigned long long batches_stamped = 0;   // batches rendered since the radiance planes were last zeroed (serial-number budget)
     int batch = 1;              // iterations in flight per launch sequence
     pt::IterState *d_state = nullptr;          // PT_MAX_SEQUENCES of them
     bool image_valid = false;   // framebuffer holds iterations 1..k of the current frame
@@ -1621,6 +1622,20 @@ int pt_render(pt_ctx *c, int iter_first, int iter_count)
             HIP_TRY(hipGraphInstantiate(&c->graph_exec[gs], c->graph[gs], nullptr, nullptr, 0));
         }
     }
+    // Serial numbers stamp the radiance-plane entries (32 bits, + PT_MAX_SEQUENCES per batch): long before they could come
+    // round again -- 2^29 batches of one context, weeks of rendering -- the planes are zeroed and the count starts over.
+    static const unsigned long long serial_budget =
+        (getenv("PT_SERIAL_BUDGET") && atoll(getenv("PT_SERIAL_BUDGET")) > 0) ? (unsigned long long)atoll(getenv("PT_SERIAL_BUDGET")) : (1ull << 29);   // (the override: tests)
+    if (c->batches_stamped + (unsigned long long)nb > serial_budget) {
+        HIP_TRY(hipStreamSynchronize(s));
+        for (int sq = 1; sq < PT_MAX_SEQUENCES; ++sq)
+            if (c->seq_stream[sq]) HIP_TRY(hipStreamSynchronize(c->seq_stream[sq]));
+        HIP_TRY(hipMemset(c->d_lbuf, 0, c->lbuf_cap));
+        for (uint32_t sq = 0; sq < (uint32_t)PT_MAX_SEQUENCES; ++sq)
+            HIP_TRY(hipMemcpy(&c->d_state[sq].serial, &sq, sizeof sq, hipMemcpyHostToDevice));
+        c->batches_stamped = 0;
+    }
+    c->batches_stamped += (unsigned long long)nb;
     if (c->timers.size() >= 1024) { rc = fold_timers(c); if (rc != PT_OK) return rc; }
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreateWithFlags(&e0, hipEventDisableSystemFence));
@@ -1690,6 +1705,7 @@ int pt_render_profiled(pt_ctx *c, int iter_first, int iter_count, double *bounce
         rc = enqueue_batch(c, s, ev.data());
         if (rc != PT_OK) return rc;
         launches++;
+        c->batches_stamped++;
         HIP_TRY(hipStreamSynchronize(s));
         for (int b = 0; b < depth; ++b) {
             float ms = 0.0f;

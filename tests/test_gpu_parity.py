@@ -173,6 +173,38 @@ def test_launch_sequences_many_small_batches(pkg):
     check(b, c, lb, lc, "96 one-iteration batches on two sequences")
 
 
+def test_radiance_plane_serials_start_over(pkg):
+    """The radiance-plane entries carry 32-bit batch serial numbers; long before they could come round again the library
+    zeroes the planes and restarts the count.  PT_SERIAL_BUDGET=3 (read when the library first renders in this process)
+    forces that between pt_render calls: a child process renders 14 iterations in 7 calls and must match the oracle."""
+    import subprocess
+    code = """
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'tests'))
+import numpy as np
+from __graft_entry__ import load_package
+pkg = load_package()
+sc = pkg.SceneFile(os.path.join({root!r}, 'scenes', 'sampleScene_spec.txt'))
+sc.set_resolution(96, 64)
+with pkg.Renderer(0) as r:
+    r.set_options(depth=4, batch=1)
+    r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
+    r.set_camera(sc.camera)
+    r.clear_image()
+    for k in range(7):
+        r.render(1 + 2 * k, 2)
+    np.save(sys.argv[1], r.download_image())
+""".format(root=ROOT)
+    out = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else ROOT
+    path = os.path.join(out, "_serial_budget_test.npy")
+    res = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, PT_SERIAL_BUDGET="3"), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    g = np.load(path)
+    os.remove(path)
+    c, _ = cpu_render("sampleScene_spec.txt", 96, 64, 4, iters=14)
+    assert np.array_equal(g.view(np.uint32), c.view(np.uint32))
+
+
 def test_launch_sequences_across_calls_and_features(pkg):
     """Two sequences in flight over several pt_render calls (resume), with direct lighting (planes accumulate along the
     path) and on the batched walk: same bits as the oracle."""
