@@ -173,7 +173,7 @@ def test_launch_sequences_many_small_batches(pkg):
     check(b, c, lb, lc, "96 one-iteration batches on two sequences")
 
 
-def test_radiance_plane_serials_start_over(pkg):
+def test_radiance_plane_serials_start_over(pkg, tmp_path):
     """The radiance-plane entries carry 32-bit batch serial numbers; long before they could come round again the library
     zeroes the planes and restarts the count.  PT_SERIAL_BUDGET=3 (read when the library first renders in this process)
     forces that between pt_render calls: a child process renders 14 iterations in 7 calls and must match the oracle."""
@@ -195,12 +195,10 @@ with pkg.Renderer(0) as r:
         r.render(1 + 2 * k, 2)
     np.save(sys.argv[1], r.download_image())
 """.format(root=ROOT)
-    out = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else ROOT
-    path = os.path.join(out, "_serial_budget_test.npy")
+    path = str(tmp_path / "serial_budget_test.npy")
     res = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, PT_SERIAL_BUDGET="3"), capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     g = np.load(path)
-    os.remove(path)
     c, _ = cpu_render("sampleScene_spec.txt", 96, 64, 4, iters=14)
     assert np.array_equal(g.view(np.uint32), c.view(np.uint32))
 
