@@ -26,6 +26,10 @@ CASES = [
     ("cloud256", "cloud256.txt", 1, 64, 36, 6, 1, {"seed": 5}),
     ("thin_lens", "sampleScene_spec.txt", 1, 72, 54, 5, 2, {"lens_radius": 0.3, "focal_distance": 11.0}),
     ("subsurface", "sss_blobs.txt", 1, 72, 72, 10, 2, {"scatter": 1}),
+    # round 3 (options with a leading underscore are handled by run() / the GPU test, not passed to the renderer as they are):
+    # an emissive MESH geom as a light of the table; motion blur with a shutter time per ray over 2 segments (frames 0 -> 1)
+    ("mesh_light", "mesh_light.txt", 1, 80, 64, 5, 2, {"direct_light": 1, "rr_start": 2, "_meshes": 1}),
+    ("motion_per_ray", "sampleScene_anim.txt", 1, 80, 60, 5, 3, {"_knots": 2}),
 ]
 
 
@@ -33,7 +37,13 @@ def run(case):
     name, scene, rotat, W, H, depth, iters, opts = case
     sc = O.LoadedScene(os.path.join(ROOT, "scenes", scene), rotat)
     sc.set_resolution(W, H)
-    img, live = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, depth, iters=iters, **opts)
+    kw = {k: v for k, v in opts.items() if not k.startswith("_")}
+    if opts.get("_meshes"):
+        kw["meshes"] = sc.meshes
+    if opts.get("_knots"):
+        nxt = O.LoadedScene(os.path.join(ROOT, "scenes", scene), rotat, frame=1)
+        kw["knot_geoms"], kw["knot_cams"] = O.motion_knots(sc.geoms, nxt.geoms, sc.n_objects, sc.camera, nxt.camera, opts["_knots"], rotat)
+    img, live = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, depth, iters=iters, **kw)
     return {"scene": scene, "rotat": rotat, "width": W, "height": H, "depth": depth, "iterations": iters, "options": opts,
             "sha256": hashlib.sha256(img.tobytes()).hexdigest(), "live_in": [int(x) for x in live],
             "mean_rgb": [float(x) for x in img.mean(axis=(0, 1))]}

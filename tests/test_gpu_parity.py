@@ -1143,8 +1143,26 @@ def test_gpu_image_hashes_to_the_committed_golden(pkg, name):
     image + live-ray counts, generated by oracle/make_render_golden.py), not only against the oracle run at test time."""
     import hashlib
     c = _golden_cases()[name]
-    img, live, _ = gpu_render(pkg, c["scene"], c["width"], c["height"], c["depth"], iters=c["iterations"], rotat=c["rotat"],
-                              **c["options"])
+    opts = {k: v for k, v in c["options"].items() if not k.startswith("_")}
+    if any(k.startswith("_") for k in c["options"]):
+        # round 3's cases: MESH triangles (the library's own .obj loader) / knot states of per-ray motion blur (frames 0 -> 1)
+        sc = pkg.SceneFile(os.path.join(SCENES, c["scene"]), c["rotat"])
+        sc.set_resolution(c["width"], c["height"])
+        with pkg.Renderer(0) as r:
+            r.set_options(depth=c["depth"], motion_per_ray=1 if c["options"].get("_knots") else 0, **opts)
+            r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
+            if c["options"].get("_meshes"):
+                r.set_meshes(sc.meshes)
+            r.set_camera(sc.camera)
+            if c["options"].get("_knots"):
+                nxt = pkg.SceneFile(os.path.join(SCENES, c["scene"]), c["rotat"], frame=1)
+                r.set_motion(nxt.geoms, nxt.camera, c["options"]["_knots"], c["rotat"])
+            r.clear_image()
+            r.render(1, c["iterations"])
+            img = r.download_image()
+            live = [int(x) for x in r.stats().live_in[:c["depth"]]]
+    else:
+        img, live, _ = gpu_render(pkg, c["scene"], c["width"], c["height"], c["depth"], iters=c["iterations"], rotat=c["rotat"], **opts)
     assert live == c["live_in"]
     assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == c["sha256"]
 
