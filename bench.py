@@ -456,6 +456,7 @@ def main():
             },
         }
         if value_pipelined is not None:
+            out["value_serial_gather"] = value          # (= `value`: the gather of the rendered frame behind the K steps)
             out["value_pipelined_gather"] = value_pipelined
             out["value_pipelined_gather_note"] = ("second region: the previous frame's tiles gathered on RCCL's stream while the "
                                                   "next K steps render (steady state of an animation); `value` has the gather of "
