@@ -77,7 +77,8 @@ def parse():
     ap.add_argument("--no-compaction", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="iterations in flight per launch sequence (0 = library default)")
     ap.add_argument("--sequences", type=int, default=0, help="launch sequences in flight (0 = library default 2)")
-    ap.add_argument("--dist-timeout", type=float, default=120.0, help="N > 1: seconds a rank waits for the others before giving up")
+    ap.add_argument("--dist-timeout", type=float, default=600.0,
+                    help="N > 1: seconds a rank waits for the others before giving up (a fresh box pages torch in for a minute or two)")
     ap.add_argument("--compaction", type=int, default=1, help="1 per-wave sharded (default), 2 workgroup scan, 0 off")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--direct-light", action="store_true", help="explicit light sampling (not the headline workload)")
