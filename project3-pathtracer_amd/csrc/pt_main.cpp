@@ -178,7 +178,7 @@ int main(int argc, char **argv)
 
     // This driver reads renderCam->image only when a frame's last iteration is done (as src/main.cpp:114-125 does), so
     // the binding may render iterations in batches and skip the per-call image copy; the environment still overrides.
-    pt_shim_configure(getenv("PT_SHIM_BATCH") ? atoi(getenv("PT_SHIM_BATCH")) : 16,
+    pt_shim_configure(getenv("PT_SHIM_BATCH") ? atoi(getenv("PT_SHIM_BATCH")) : 64,     // (four batches of 16: both launch sequences at work)
                       getenv("PT_READBACK_EVERY") ? atoi(getenv("PT_READBACK_EVERY")) : 0);
     pt_shim_set_motion(motion >= 0 ? motion : (getenv("PT_MOTION_SLICES") ? atoi(getenv("PT_MOTION_SLICES")) : 0), rotat);
     const auto t0 = chrono::steady_clock::now();

@@ -31,7 +31,7 @@
 //                         which is when src/main.cpp:114-125 reads it)
 // The defaults reproduce the reference call for call: every iteration is rendered and renderCam->image updated
 // before cudaRaytraceCore returns.  A caller that only reads the image at the end (src/main.cpp does) may opt in to
-// deferral with pt_shim_configure(16, 0) -- the headless driver pt_main.cpp does -- and must then call
+// deferral with pt_shim_configure(64, 0) -- the headless driver pt_main.cpp does -- and must then call
 // pt_shim_flush() if it stops before iterations == renderCam->iterations: that renders what is still pending and
 // copies the image back, so no accepted iteration is lost.
 #include <stdio.h>
