@@ -163,6 +163,26 @@ def test_launch_sequences_in_flight_are_invisible(pkg, batch, iters):
     assert sa.iterations == sb.iterations == iters
 
 
+def test_launch_sequences_eager_launches_and_strip_tiles(pkg):
+    """Two sequences without hipGraphs (use_graph = 0: eager launches on both streams) and on an interleaved-strip tile
+    (global pixel numbering), several batches: the tile's rows of the oracle's frame, bit for bit."""
+    from project3_pathtracer_amd import sharding
+    W, H, depth, iters = 128, 72, 5, 23
+    c, _ = cpu_render("sampleScene_spec.txt", W, H, depth, iters=iters, rr_start=1)
+    for use_graph in (0, 1):
+        sc = pkg.SceneFile(os.path.join(SCENES, "sampleScene_spec.txt"))
+        sc.set_resolution(W, H)
+        with pkg.Renderer(0) as r:
+            r.set_options(depth=depth, rr_start=1, batch=4, sequences=2, use_graph=use_graph, strip_rows=8, strip_world=3, strip_rank=1)
+            r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
+            r.set_camera(sc.camera)
+            r.clear_image()
+            r.render(1, iters)
+            g = r.download_image()
+        want = c[sharding.strip_global_rows(H, 3, 1, 8)]
+        assert np.array_equal(g.view(np.uint32), want.view(np.uint32)), f"use_graph={use_graph}"
+
+
 def test_launch_sequences_many_small_batches(pkg):
     """96 one-iteration batches alternate between the two sequences: 95 cross-stream hand-overs of the framebuffer (each
     accumulate waits for the other stream's previous one).  Same bits as one sequence and as the oracle."""
