@@ -1242,6 +1242,36 @@ int build_slices(pt_ctx *c)
     return PT_OK;
 }
 
+// One batch (count <= the context's batch size) of context c on stream ss, for a caller that keeps several contexts busy on two
+// streams (motion blur by slices): bookkeeping and bounce launches as soon as the stream gets to them, the accumulate behind
+// `wait_ev` (the previous batch's accumulate, possibly on the other stream; nullptr: none), `done_ev` recorded behind it.
+int render_batch_ordered(pt_ctx *c, hipStream_t ss, int iter_first, int count, hipEvent_t wait_ev, hipEvent_t done_ev)
+{
+    int rc = configure(c);
+    if (rc != PT_OK) return rc;
+    if (count < 1 || count > c->batch) return fail(PT_ERR_INVALID, "render_batch_ordered: %d iterations (batch %d)", count, c->batch);
+    if (c->opt.use_graph && !c->graph_exec[0]) {        // slot 0: sequence 0's batch without its accumulate (as in pt_render)
+        HIP_TRY(hipStreamBeginCapture(ss, hipStreamCaptureModeThreadLocal));
+        rc = enqueue_batch(c, ss, nullptr, 0, false);
+        hipError_t ce = hipStreamEndCapture(ss, &c->graph[0]);
+        if (rc != PT_OK) { drop_graph(c); return rc; }
+        if (ce != hipSuccess) { drop_graph(c); return fail(PT_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce)); }
+        HIP_TRY(hipGraphInstantiate(&c->graph_exec[0], c->graph[0], nullptr, nullptr, 0));
+    }
+    HIP_TRY(pt::launch_iter_set(ss, c->d_state, (uint32_t)iter_first, (uint32_t)count, 0u, 0u, 1u));
+    if (c->opt.use_graph) HIP_TRY(hipGraphLaunch(c->graph_exec[0], ss));
+    else { rc = enqueue_batch(c, ss, nullptr, 0, false); if (rc != PT_OK) return rc; }
+    if (wait_ev) HIP_TRY(hipStreamWaitEvent(ss, wait_ev, 0));
+    const pt::KParams &ks = c->kps[0];
+    HIP_TRY(pt::launch_accumulate(ss, ks.image, ks.lbuf, ks.st, ks.npix));
+    HIP_TRY(pt::launch_iter_fold(ss, c->d_state, c->kp.depth));
+    if (done_ev) HIP_TRY(hipEventRecord(done_ev, ss));
+    c->batches_stamped++;
+    c->bounce_launches += (unsigned long long)c->kp.depth;
+    c->image_valid = true;
+    return PT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1579,6 +1609,45 @@ int pt_render(pt_ctx *c, int iter_first, int iter_count)
         for (pt_ctx *ch : c->slice_ctx) {
             if (ch->d_image_bound != image_ptr(c)) { rc = pt_bind_image(ch, image_ptr(c)); if (rc != PT_OK) return rc; }
             if (ch->stream != s) { rc = pt_set_stream(ch, (void *)s); if (rc != PT_OK) return rc; }
+        }
+        // Consecutive runs belong to different slices -- different contexts with pools of their own --, so they alternate
+        // between the render stream and a second one like the launch sequences of a static scene do: a run's launches fill
+        // the tails of its neighbour's, only the accumulates into the shared framebuffer are chained (iteration order).
+        // (A child whose batch is smaller than a run -- huge tiles -- takes the plain, serial path.)
+        bool two_streams = c->nseq > 1;
+        for (pt_ctx *ch : c->slice_ctx) {
+            rc = configure(ch);
+            if (rc != PT_OK) return rc;
+            if (ch->batch < PT_SLICE_ITERATIONS) two_streams = false;
+        }
+        if (two_streams) {
+            if (!c->seq_stream[1]) HIP_TRY(hipStreamCreateWithFlags(&c->seq_stream[1], hipStreamNonBlocking));
+            for (int sq = 0; sq < 2; ++sq)
+                if (!c->seq_acc[sq]) HIP_TRY(hipEventCreateWithFlags(&c->seq_acc[sq], hipEventDisableTiming | hipEventDisableSystemFence));
+            if (!c->seq_fork) HIP_TRY(hipEventCreateWithFlags(&c->seq_fork, hipEventDisableTiming | hipEventDisableSystemFence));
+            if (c->timers.size() >= 1024) { rc = fold_timers(c); if (rc != PT_OK) return rc; }
+            hipEvent_t e0, e1;
+            HIP_TRY(hipEventCreateWithFlags(&e0, hipEventDisableSystemFence));
+            HIP_TRY(hipEventCreateWithFlags(&e1, hipEventDisableSystemFence));
+            c->timers.emplace_back(e0, e1);
+            HIP_TRY(hipEventRecord(e0, s));
+            HIP_TRY(hipEventRecord(c->seq_fork, s));
+            HIP_TRY(hipStreamWaitEvent(c->seq_stream[1], c->seq_fork, 0));
+            int j = 0;
+            for (int it = iter_first; it < iter_first + iter_count; ++j) {
+                const int run = (it - 1) / PT_SLICE_ITERATIONS;
+                int end = (run + 1) * PT_SLICE_ITERATIONS + 1;
+                if (end > iter_first + iter_count) end = iter_first + iter_count;
+                hipStream_t ss = (j & 1) ? c->seq_stream[1] : s;
+                rc = render_batch_ordered(c->slice_ctx[(size_t)(run % c->motion_slices)], ss, it, end - it,
+                                          j > 0 ? c->seq_acc[(j - 1) & 1] : nullptr, c->seq_acc[j & 1]);
+                if (rc != PT_OK) return rc;
+                it = end;
+            }
+            if (j > 1) HIP_TRY(hipStreamWaitEvent(s, c->seq_acc[1], 0));        // join (the last event of the second stream)
+            HIP_TRY(hipEventRecord(e1, s));
+            c->image_valid = true;
+            return PT_OK;
         }
         for (int it = iter_first; it < iter_first + iter_count;) {
             const int run = (it - 1) / PT_SLICE_ITERATIONS;
