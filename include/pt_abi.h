@@ -124,10 +124,12 @@ typedef struct pt_options {
                              are ordered (iteration order), so the image does not depend on it */
     int motion_per_ray;   /* motion blur (pt_set_motion): 0 = one scene state per run of 16 iterations (default, every scene);
                              1 = a shutter time PER RAY: every path draws its time as the third number of its camera stream
-                             and sees, at all bounces, matrices (and camera vectors) interpolated entry-wise between the two
-                             of `slices` + 1 knot states around it -- exact for translations, a chord approximation of
-                             rotations that tightens with `slices`.  Scalar geometry path only (geom_path 0 or 1); excludes
-                             meshes, direct lighting and scattering */
+                             and sees, at all bounces, the transforms (and camera vectors) interpolated entry-wise between the two
+                             of `slices` + 1 knot states around it, with their inverses computed from them -- exact for
+                             translations, a chord approximation of
+                             rotations that tightens with `slices`.  Runs on the pair queue (up to 40 primitives, or geom_path 5:
+                             pre-test against boxes swept over the shutter interval) and on the scalar loop (geom_path 1);
+                             excludes meshes, direct lighting and scattering */
 } pt_options;
 
 typedef struct pt_stats {

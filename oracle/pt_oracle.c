@@ -786,8 +786,29 @@ static float lerp1f(float a, float b, float f) { return a + (b - a) * f; }
 static o_vec3 lerp3f(o_vec3 a, o_vec3 b, float f) { return v3(lerp1f(a.x, b.x, f), lerp1f(a.y, b.y, f), lerp1f(a.z, b.z, f)); }
 static o_vec4 lerp4f(o_vec4 a, o_vec4 b, float f) { o_vec4 r; r.x = lerp1f(a.x, b.x, f); r.y = lerp1f(a.y, b.y, f); r.z = lerp1f(a.z, b.z, f); r.w = lerp1f(a.w, b.w, f); return r; }
 
+/* spec (per-ray motion blur): inverse of an affine transform given by rows 0..2 (a | a3), (b | b3), (c | c3): adjugate over
+ * determinant for the 3x3 part, then -inverse * translation; fp32, this operation order (the HIP kernels run the same) */
+void o_affineInverse(const o_mat4 *m, o_mat4 *out)
+{
+    const float a0 = m->x.x, a1 = m->x.y, a2 = m->x.z, a3 = m->x.w;
+    const float b0 = m->y.x, b1 = m->y.y, b2 = m->y.z, b3 = m->y.w;
+    const float c0 = m->z.x, c1 = m->z.y, c2 = m->z.z, c3 = m->z.w;
+    const float k00 = b1 * c2 - b2 * c1, k01 = b2 * c0 - b0 * c2, k02 = b0 * c1 - b1 * c0;
+    const float det = (a0 * k00 + a1 * k01) + a2 * k02;
+    const float id = 1.0f / det;
+    out->x.x = k00 * id; out->x.y = (a2 * c1 - a1 * c2) * id; out->x.z = (a1 * b2 - a2 * b1) * id;
+    out->y.x = k01 * id; out->y.y = (a0 * c2 - a2 * c0) * id; out->y.z = (a2 * b0 - a0 * b2) * id;
+    out->z.x = k02 * id; out->z.y = (a1 * c0 - a0 * c1) * id; out->z.z = (a0 * b1 - a1 * b0) * id;
+    out->x.w = -((out->x.x * a3 + out->x.y * b3) + out->x.z * c3);
+    out->y.w = -((out->y.x * a3 + out->y.y * b3) + out->y.z * c3);
+    out->z.w = -((out->z.x * a3 + out->z.y * b3) + out->z.z * c3);
+    out->w.x = 0.0f; out->w.y = 0.0f; out->w.z = 0.0f; out->w.w = 1.0f;
+}
+
 /* spec (per-ray motion blur): the scene a path with shutter draw u_t sees -- segment k = min(floor(u_t * K), K - 1) of the
- * K = n_knots - 1 between the knots, f = u_t * K - k, rows 0..2 of both matrices (and the camera vectors) a + (b - a) * f */
+ * K = n_knots - 1 between the knots, f = u_t * K - k, rows 0..2 of the TRANSFORM (and the camera vectors) a + (b - a) * f,
+ * the inverse transform computed from that (o_affineInverse): the object a ray meets is exactly the interpolated transform's
+ * image of the unit shape -- a point of it is the convex combination of its places at the two knots */
 static void scene_at_time(const motion_knots *mk, int nG, float u_t, o_staticGeom *out, cam_basis *cb, const o_cameraData *cam0)
 {
     const int K = mk->n_knots - 1;
@@ -801,9 +822,7 @@ static void scene_at_time(const motion_knots *mk, int nG, float u_t, o_staticGeo
         out[g].transform.x = lerp4f(A[g].transform.x, B[g].transform.x, f);
         out[g].transform.y = lerp4f(A[g].transform.y, B[g].transform.y, f);
         out[g].transform.z = lerp4f(A[g].transform.z, B[g].transform.z, f);
-        out[g].inverseTransform.x = lerp4f(A[g].inverseTransform.x, B[g].inverseTransform.x, f);
-        out[g].inverseTransform.y = lerp4f(A[g].inverseTransform.y, B[g].inverseTransform.y, f);
-        out[g].inverseTransform.z = lerp4f(A[g].inverseTransform.z, B[g].inverseTransform.z, f);
+        o_affineInverse(&out[g].transform, &out[g].inverseTransform);
     }
     if (mk->knot_cams) {
         const o_cameraData *ca = &mk->knot_cams[k], *cn = ca + 1;

@@ -444,6 +444,84 @@ __device__ __forceinline__ Hit nearestHitQueued(const KParams &p, const PR *s_pr
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// FEAT_MOTION: a shutter time per ray
+// ---------------------------------------------------------------------------------------------------------------
+// Every path draws its time as the third number of its camera stream and sees the scene interpolated between the two
+// knot states around it: segment k of the nknots - 1 between the knots and the fraction f inside it.  Nothing about a
+// primitive is wave-uniform any more: each lane gathers the two knots' transform rows of the primitive, interpolates them
+// entry-wise, a + (b - a) * f, and inverts the result (the oracle's scene_at_time).
+struct MotionTime { uint32_t k = 0u; float f = 0.0f; };
+__device__ __forceinline__ MotionTime motionTime(const KParams &p, float u_t)
+{
+    const int K = p.nknots - 1;
+    const float tau = u_t * (float)K;
+    int k = (int)tau;
+    if (k > K - 1) k = K - 1;
+    MotionTime mt;
+    mt.k = (uint32_t)k;
+    mt.f = tau - (float)k;
+    return mt;
+}
+// rows 0..2 of the transform of primitive g at the lane's time -- the two knots' rows interpolated entry-wise -- and of its inverse,
+// computed from them: adjugate over determinant for the 3x3 part, then -inverse * translation, in the oracle's operation order
+// (o_affineInverse).  The object a ray meets is then exactly the interpolated transform's image of the unit shape.
+__device__ __forceinline__ void motionRows(const KParams &p, uint32_t g, MotionTime mt, float *inv, float *fwd)
+{
+    const float4 *A = reinterpret_cast<const float4 *>(p.knots) + ((size_t)mt.k * (size_t)p.nG + g) * 3u;
+    const float4 *B = A + (size_t)p.nG * 3u;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float4 a = A[r], b = B[r];
+        fwd[4 * r + 0] = a.x + (b.x - a.x) * mt.f;
+        fwd[4 * r + 1] = a.y + (b.y - a.y) * mt.f;
+        fwd[4 * r + 2] = a.z + (b.z - a.z) * mt.f;
+        fwd[4 * r + 3] = a.w + (b.w - a.w) * mt.f;
+    }
+    const float a0 = fwd[0], a1 = fwd[1], a2 = fwd[2], a3 = fwd[3], b0 = fwd[4], b1 = fwd[5], b2 = fwd[6], b3 = fwd[7];
+    const float c0 = fwd[8], c1 = fwd[9], c2 = fwd[10], c3 = fwd[11];
+    const float k00 = b1 * c2 - b2 * c1, k01 = b2 * c0 - b0 * c2, k02 = b0 * c1 - b1 * c0;
+    const float det = (a0 * k00 + a1 * k01) + a2 * k02;
+    const float id = rcp_rn(det);
+    inv[0] = k00 * id; inv[1] = (a2 * c1 - a1 * c2) * id; inv[2] = (a1 * b2 - a2 * b1) * id;
+    inv[4] = k01 * id; inv[5] = (a0 * c2 - a2 * c0) * id; inv[6] = (a2 * b0 - a0 * b2) * id;
+    inv[8] = k02 * id; inv[9] = (a1 * c0 - a0 * c1) * id; inv[10] = (a0 * b1 - a1 * b0) * id;
+    inv[3] = -((inv[0] * a3 + inv[1] * b3) + inv[2] * c3);
+    inv[7] = -((inv[4] * a3 + inv[5] * b3) + inv[6] * c3);
+    inv[11] = -((inv[8] * a3 + inv[9] * b3) + inv[10] * c3);
+}
+__device__ __forceinline__ Hit nearestHitMotion(const KParams &p, f3 o, f3 d, MotionTime mt)
+{
+    Hit h;
+    h.any = false;
+    h.material = 0;
+    h.prim = 0;
+    h.p = mk(0, 0, 0);
+    h.n = mk(0, 0, 0);
+    float best_t = 0.0f;
+    for (int g = 0; g < p.nG; ++g) {
+        const_u32_ptr hp = (const_u32_ptr)(uintptr_t)(p.prims + g);
+        const uint32_t type = hp[0], mat = hp[1];
+        if (type > 1u) continue;
+        Prim P;
+        P.type = type;
+        motionRows(p, (uint32_t)g, mt, P.inv, P.fwd);
+        P.cx = P.fwd[3]; P.cy = P.fwd[7]; P.cz = P.fwd[11];      // transform * (0,0,0,1): the translation column, exactly
+        f3 ip, in;
+        const float t = intersectPrim<false>(P, o, d, o, ip, in);
+        if (t > 0 && (!h.any || t < best_t)) {                    // smallest t > 0, ties keep the lowest index
+            h.any = true;
+            best_t = t;
+            h.p = ip;
+            h.n = in;
+            h.material = mat;
+            h.prim = (uint32_t)g;
+        }
+    }
+    h.t = best_t;
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // GEOM_PAIR
 // ---------------------------------------------------------------------------------------------------------------
 struct PairQueue {
@@ -455,14 +533,18 @@ struct PairQueue {
     float2 *dir;                  // [64] ... (direction.y, direction.z)
     f3 po, pd;                    // org == nullptr (batched walk): the calling lane's OWN ray; a pair's lane fetches its owner's
                                   // through ds_bpermute instead of from an LDS copy (1.5 KB per wave less)
+    uint2 *mt;                    // [64] per owner lane (FEAT_MOTION only): the ray's shutter segment and fraction (MotionTime)
     unsigned long long *dbg;
 };
 static constexpr uint32_t PAIR_QUEUE_BYTES = 2 * QCAP * 4 + 64 * 8 + 2 * 64 * 16 + 64 * 8;
+static constexpr uint32_t PAIR_QUEUE_MOTION_BYTES = PAIR_QUEUE_BYTES + 64 * 8;      // + the owners' shutter times
 static_assert(PAIR_QUEUE_BYTES <= WAVE_QUEUE_BYTES, "the pair queue lives in the hit queue's LDS region");
 
 // one batch: lane l takes pair head + l of queue TYPE (0 sphere, 1 box), whoever owns it.  TYPE 2 = the last, mixed
 // batch of a chunk: lanes [0, nb) take the sphere queue's leftovers, lanes [nb, nb + nb2) the box queue's.
-template <uint32_t TYPE, bool FIRST, class PR>
+// MOTION (FEAT_MOTION, a shutter time per ray): the pair's lane interpolates ITS primitive's rows at ITS owner's time from the
+// knot states instead of reading the static record.
+template <uint32_t TYPE, bool FIRST, class PR, bool MOTION = false>
 __device__ __forceinline__ void pairBatch(const KParams &p, const PR *s_prims, const PairQueue &q, uint32_t head, uint32_t nb,
                                           uint32_t lane, uint32_t head2 = 0u, uint32_t nb2 = 0u)
 {
@@ -495,8 +577,18 @@ __device__ __forceinline__ void pairBatch(const KParams &p, const PR *s_prims, c
             d = mk(oo.w, dd.x, dd.y);
         }
         const float4 *iv = reinterpret_cast<const float4 *>(s_prims[prim].inv);
-        const float4 i0 = iv[0], i1 = iv[1], i2 = iv[2];
-        const float inv[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
+        float inv[12], mfwd[12];
+        if (MOTION) {
+            const uint2 tm = q.mt[owner];
+            MotionTime mt;
+            mt.k = tm.x;
+            mt.f = __uint_as_float(tm.y);
+            motionRows(p, prim, mt, inv, mfwd);
+        } else {
+            const float4 i0 = iv[0], i1 = iv[1], i2 = iv[2];
+            inv[0] = i0.x; inv[1] = i0.y; inv[2] = i0.z; inv[3] = i0.w; inv[4] = i1.x; inv[5] = i1.y; inv[6] = i1.z; inv[7] = i1.w;
+            inv[8] = i2.x; inv[9] = i2.y; inv[10] = i2.z; inv[11] = i2.w;
+        }
         f3 ro = o, rd;
         if (FIRST) {                                         // camera rays: inverseTransform*(eye,1) comes from the host
             const float4 re = reinterpret_cast<const float4 *>(p.ro_eye)[prim];
@@ -510,6 +602,7 @@ __device__ __forceinline__ void pairBatch(const KParams &p, const PR *s_prims, c
             f3 real;
             float dist;
             if (TYPE == 3u) dist = hitPointTriangle(o, ro, rd, t, real);
+            else if (MOTION) dist = hitPoint(mfwd, o, ro, rd, t, real);
             else {
                 const float4 f0 = iv[3], f1 = iv[4], f2 = iv[5];          // fwd rows follow the inverse rows
                 const float fwd[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
@@ -528,14 +621,16 @@ __device__ __forceinline__ void pairBatch(const KParams &p, const PR *s_prims, c
 }
 
 // Must be entered by all 64 lanes of the wave (lanes without a ray pass valid = false).
-template <bool FIRST, class PR>
+// MOTION: s_boxes holds the primitives' boxes swept over the shutter interval (host), mymt = the calling lane's shutter time.
+template <bool FIRST, class PR, bool MOTION = false>
 __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_prims, const float4 *s_boxes, const PairQueue q,
-                                               f3 o, f3 d, bool valid, uint32_t lane, uint32_t primmask)
+                                               f3 o, f3 d, bool valid, uint32_t lane, uint32_t primmask, MotionTime mymt = MotionTime())
 {
     const unsigned long long ph_in = (DEBUG_PHASE2 && !FIRST) ? __builtin_amdgcn_s_memtime() : 0ull;
     q.key[lane] = KEY_NONE;
     q.org[lane] = make_float4(o.x, o.y, o.z, d.x);
     q.dir[lane] = make_float2(d.y, d.z);
+    if (MOTION) q.mt[lane] = make_uint2(mymt.k, __float_as_uint(mymt.f));
     uint32_t head[2] = {0u, 0u}, tail[2] = {0u, 0u};        // wave-uniform
     const uint64_t vmask = __ballot(valid);
     const f3 dinv = approxInverse(d);
@@ -569,11 +664,11 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
         if (type == 0u) {                                    // wave-uniform
             if (pass) q.q[0][(tail[0] + rank) & (QCAP - 1u)] = lane | ((uint32_t)g << 8);
             tail[0] += (uint32_t)__popcll(mask);
-            if (tail[0] - head[0] >= 64u) { pairBatch<0u, FIRST>(p, s_prims, q, head[0], 64u, lane); head[0] += 64u; }
+            if (tail[0] - head[0] >= 64u) { pairBatch<0u, FIRST, PR, MOTION>(p, s_prims, q, head[0], 64u, lane); head[0] += 64u; }
         } else {
             if (pass) q.q[1][(tail[1] + rank) & (QCAP - 1u)] = lane | ((uint32_t)g << 8);
             tail[1] += (uint32_t)__popcll(mask);
-            if (tail[1] - head[1] >= 64u) { pairBatch<1u, FIRST>(p, s_prims, q, head[1], 64u, lane); head[1] += 64u; }
+            if (tail[1] - head[1] >= 64u) { pairBatch<1u, FIRST, PR, MOTION>(p, s_prims, q, head[1], 64u, lane); head[1] += 64u; }
         }
     }
     const uint64_t dbg_valid = DEBUG_PAIR ? __ballot(valid) : 0ull;
@@ -587,10 +682,10 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
     const unsigned long long ph_a = (DEBUG_PHASE2 && !FIRST) ? __builtin_amdgcn_s_memtime() : 0ull;
     const uint32_t left0 = tail[0] - head[0], left1 = tail[1] - head[1];      // both < 64
     if (left0 != 0u && left1 != 0u && left0 + left1 <= 64u) {
-        pairBatch<2u, FIRST>(p, s_prims, q, head[0], left0, lane, head[1], left1);   // one mixed batch instead of two partial ones
+        pairBatch<2u, FIRST, PR, MOTION>(p, s_prims, q, head[0], left0, lane, head[1], left1);   // one mixed batch instead of two partial ones
     } else {
-        if (left0 != 0u) pairBatch<0u, FIRST>(p, s_prims, q, head[0], left0, lane);
-        if (left1 != 0u) pairBatch<1u, FIRST>(p, s_prims, q, head[1], left1, lane);
+        if (left0 != 0u) pairBatch<0u, FIRST, PR, MOTION>(p, s_prims, q, head[0], left0, lane);
+        if (left1 != 0u) pairBatch<1u, FIRST, PR, MOTION>(p, s_prims, q, head[1], left1, lane);
     }
     wave_lds_fence();
     Hit h;
@@ -616,7 +711,12 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
         h.t = __uint_as_float((uint32_t)(k >> 32));
         h.p = mk(b.x, b.y, b.z);
         h.material = P.material;
-        if (P.type == 0u) {
+        if (MOTION) {
+            // the winner's transform at this lane's time: sphere centre = its translation column, box normal from its rows
+            float minv[12], mfwd[12];
+            motionRows(p, prim, mymt, minv, mfwd);
+            h.n = (P.type == 0u) ? sphereNormal(h.p, mk(mfwd[3], mfwd[7], mfwd[11])) : boxNormal(mfwd, face);
+        } else if (P.type == 0u) {
             const float4 c = *reinterpret_cast<const float4 *>(&P.cx);
             h.n = sphereNormal(h.p, mk(c.x, c.y, c.z));
         } else {
@@ -1013,77 +1113,11 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
     return h;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// FEAT_MOTION: a shutter time per ray
-// ---------------------------------------------------------------------------------------------------------------
-// Every path draws its time as the third number of its camera stream and sees the scene interpolated between the two
-// knot states around it: segment k of the nknots - 1 between the knots and the fraction f inside it.  Nothing about a
-// primitive is wave-uniform any more: each lane gathers the two knots' rows of the primitive and interpolates them
-// entry-wise, a + (b - a) * f (the oracle's scene_at_time).
-struct MotionTime { uint32_t k; float f; };
-__device__ __forceinline__ MotionTime motionTime(const KParams &p, float u_t)
-{
-    const int K = p.nknots - 1;
-    const float tau = u_t * (float)K;
-    int k = (int)tau;
-    if (k > K - 1) k = K - 1;
-    MotionTime mt;
-    mt.k = (uint32_t)k;
-    mt.f = tau - (float)k;
-    return mt;
-}
-// rows 0..2 of inverseTransform and transform of primitive g at the lane's time
-__device__ __forceinline__ void motionRows(const KParams &p, uint32_t g, MotionTime mt, float *inv, float *fwd)
-{
-    const float4 *A = reinterpret_cast<const float4 *>(p.knots) + ((size_t)mt.k * (size_t)p.nG + g) * 6u;
-    const float4 *B = A + (size_t)p.nG * 6u;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-        const float4 a = A[r], b = B[r];
-        float *dst = (r < 3) ? inv + 4 * r : fwd + 4 * (r - 3);
-        dst[0] = a.x + (b.x - a.x) * mt.f;
-        dst[1] = a.y + (b.y - a.y) * mt.f;
-        dst[2] = a.z + (b.z - a.z) * mt.f;
-        dst[3] = a.w + (b.w - a.w) * mt.f;
-    }
-}
-__device__ __forceinline__ Hit nearestHitMotion(const KParams &p, f3 o, f3 d, MotionTime mt)
-{
-    Hit h;
-    h.any = false;
-    h.material = 0;
-    h.prim = 0;
-    h.p = mk(0, 0, 0);
-    h.n = mk(0, 0, 0);
-    float best_t = 0.0f;
-    for (int g = 0; g < p.nG; ++g) {
-        const_u32_ptr hp = (const_u32_ptr)(uintptr_t)(p.prims + g);
-        const uint32_t type = hp[0], mat = hp[1];
-        if (type > 1u) continue;
-        Prim P;
-        P.type = type;
-        motionRows(p, (uint32_t)g, mt, P.inv, P.fwd);
-        P.cx = P.fwd[3]; P.cy = P.fwd[7]; P.cz = P.fwd[11];      // transform * (0,0,0,1): the translation column, exactly
-        f3 ip, in;
-        const float t = intersectPrim<false>(P, o, d, o, ip, in);
-        if (t > 0 && (!h.any || t < best_t)) {                    // smallest t > 0, ties keep the lowest index
-            h.any = true;
-            best_t = t;
-            h.p = ip;
-            h.n = in;
-            h.material = mat;
-            h.prim = (uint32_t)g;
-        }
-    }
-    h.t = best_t;
-    return h;
-}
-
 // nearest hit of (o, d) for the lanes with want == true, by the GEOM path.  Every lane of the wave must make the call
 // (the hit queue uses all 64 lanes as workers whatever their own ray).
-template <int GEOM, bool FIRST>
+template <int GEOM, bool FIRST, bool MOTION = false>
 __device__ __forceinline__ Hit nearestHit(const KParams &p, const PrimPad *s_prims, const float4 *s_nodes, const WaveQueue &wq,
-                                          f3 o, f3 d, bool want, uint32_t lane, uint32_t primmask = 0xFFFFFFFFu)
+                                          f3 o, f3 d, bool want, uint32_t lane, uint32_t primmask = 0xFFFFFFFFu, MotionTime mt = MotionTime())
 {
     if (GEOM == GEOM_QUEUE) return nearestHitQueued<FIRST>(p, s_prims, wq, o, d, want, lane);
     if (GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR || GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) {
@@ -1095,6 +1129,7 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const PrimPad *s_pri
         pq.best = reinterpret_cast<float4 *>(b + 2 * QCAP * 4 + 64 * 8);
         pq.org = reinterpret_cast<float4 *>(b + 2 * QCAP * 4 + 64 * 8 + 64 * 16);
         pq.dir = reinterpret_cast<float2 *>(b + 2 * QCAP * 4 + 64 * 8 + 2 * 64 * 16);
+        pq.mt = reinterpret_cast<uint2 *>(b + PAIR_QUEUE_BYTES);           // (carved for FEAT_MOTION instances only)
         pq.dbg = p.st->dbg;
         pq.tq = nullptr;
         if (GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) {
@@ -1109,7 +1144,7 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const PrimPad *s_pri
             return nearestHitWalk4<FIRST>(p, p.prims, w4, pq, o, d, want, lane, (FIRST && p.span_off != nullptr) ? primmask : 0xFFFFFFFFu);
         }
         if (GEOM == GEOM_WALK_PAIR) return nearestHitWalkPairs<FIRST>(p, p.prims, s_nodes, pq, o, d, want, lane);
-        return nearestHitPairs<FIRST>(p, s_prims, s_nodes, pq, o, d, want, lane, primmask);
+        return nearestHitPairs<FIRST, PrimPad, MOTION>(p, s_prims, s_nodes, pq, o, d, want, lane, primmask, mt);
     }
     Hit h;
     h.any = false;
@@ -1164,7 +1199,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                                                  : (GEOM == GEOM_PAIR ? p.nG * 32 * (NEE ? 2 : 1) : 0));
     unsigned char *s_queue = smem + prim_bytes + node_bytes;
     const int WAVE_LDS = (GEOM == GEOM_QUEUE) ? (int)WAVE_QUEUE_BYTES
-                         : ((GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR) ? (int)PAIR_QUEUE_BYTES
+                         : ((GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR) ? (int)((MOTION && GEOM == GEOM_PAIR) ? PAIR_QUEUE_MOTION_BYTES : PAIR_QUEUE_BYTES)
                             : ((GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) ? (int)walk4_wave_bytes(p.ntri) : 0));
     const int queue_bytes = NW * WAVE_LDS;
     float *s_mats = reinterpret_cast<float *>(s_queue + queue_bytes);
@@ -1192,7 +1227,8 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
         for (int k = tid; k < p.nG * 8; k += WG) dst[p.nG * 9 + (k >> 3) * 9 + (k & 7)] = fsrc[k];
     }
     if (GEOM == GEOM_PAIR) {
-        const uint4 *src = reinterpret_cast<const uint4 *>((FIRST && !(p.lens_radius > 0.0f)) ? p.box_eye : p.box_world);
+        // (FEAT_MOTION: box_world holds the boxes swept over the shutter interval, and camera rays have no common eye)
+        const uint4 *src = reinterpret_cast<const uint4 *>((FIRST && !MOTION && !(p.lens_radius > 0.0f)) ? p.box_eye : p.box_world);
         uint4 *dst = reinterpret_cast<uint4 *>(smem + prim_bytes);
         for (int k = tid; k < p.nG * 2; k += WG) dst[k] = src[k];
         if (NEE) {                                           // shadow rays start anywhere: world boxes, second half
@@ -1447,7 +1483,10 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
             primmask = b0 >> 6;                                           // (the batched walks take the span's number)
         }
         Hit h;
-        if (MOTION) {
+        if (MOTION && GEOM == GEOM_PAIR) {
+            // pair path: per-lane pre-test against the swept boxes, exact tests in full batches with per-pair interpolated rows
+            h = nearestHit<GEOM, false, true>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane, 0xFFFFFFFFu, mt);
+        } else if (MOTION) {
             h.any = false; h.material = 0; h.prim = 0; h.t = 0.0f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0);
             if (valid) h = nearestHitMotion(p, o, d, mt);
         } else {
@@ -1790,8 +1829,8 @@ static const void *bounce_fn_geom(bool first, int compact, int feat)
 {
     if (feat != 0) {
         if (compact != 1) return nullptr;
-        if (feat == FEAT_MOTION) {            // per-ray shutter time: the scalar path with 256-thread workgroups only
-            if constexpr (GEOM == GEOM_SCALAR && WG == 256) return bounce_fn_feat<256, GEOM_SCALAR, FEAT_MOTION>(first);
+        if (feat == FEAT_MOTION) {            // per-ray shutter time: the scalar and the pair path, 256-thread workgroups only
+            if constexpr ((GEOM == GEOM_SCALAR || GEOM == GEOM_PAIR) && WG == 256) return bounce_fn_feat<256, GEOM, FEAT_MOTION>(first);
             return nullptr;
         }
         if ((feat & FEAT_MOTION) != 0) return nullptr;

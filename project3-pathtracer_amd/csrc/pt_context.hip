@@ -703,7 +703,7 @@ int configure(pt_ctx *c)
     }
     // motion blur with a shutter time per ray: knot states at shutter times j / slices, built as the slices are (TRS
     // interpolated component-wise, matrices rebuilt by the loader's buildTransformationMatrix); the kernels interpolate the
-    // matrices and the camera vectors entry-wise between the two knots around a ray's time
+    // transform's rows and the camera vectors entry-wise between the two knots around a ray's time and invert the result
     k.nknots = 0;
     if (motion_per_ray(c)) {
         if (nT > 0) return fail(PT_ERR_INVALID, "motion_per_ray: triangle meshes need the slice scheme (motion_per_ray = 0)");
@@ -711,10 +711,15 @@ int configure(pt_ctx *c)
             if (g.type == PT_MESH) return fail(PT_ERR_INVALID, "motion_per_ray: MESH objects need the slice scheme (motion_per_ray = 0)");
         if (o.direct_light || o.scatter) return fail(PT_ERR_INVALID, "motion_per_ray excludes direct_light and scatter (use the slice scheme)");
         if (o.compaction != 1) return fail(PT_ERR_INVALID, "motion_per_ray needs compaction 1 (got %d)", o.compaction);
-        if (!(o.geom_path == 0 || o.geom_path == 1)) return fail(PT_ERR_INVALID, "motion_per_ray runs on the scalar geometry path (geom_path 0 or 1, got %d)", o.geom_path);
+        if (!(o.geom_path == 0 || o.geom_path == 1 || o.geom_path == 5))
+            return fail(PT_ERR_INVALID, "motion_per_ray runs on the scalar and the pair-queue geometry paths (geom_path 0, 1 or 5, got %d)", o.geom_path);
         if (!(o.workgroup == 0 || o.workgroup == 256)) return fail(PT_ERR_INVALID, "motion_per_ray needs workgroup 0 or 256 (got %d)", o.workgroup);
         const int nk = c->motion_slices + 1;
-        std::vector<float> kn((size_t)nk * nGeoms * 24, 0.0f), kc((size_t)nk * 12, 0.0f);
+        std::vector<float> kn((size_t)nk * nGeoms * 12, 0.0f), kc((size_t)nk * 12, 0.0f);
+        // the primitives' padded world boxes SWEPT over the shutter interval (pair path pre-test): a point of the primitive at a
+        // time between two knots is a convex combination of its images at the knots (the rows are interpolated entry-wise),
+        // so the box around the knots' boxes holds it
+        std::vector<float> swept(nGeoms * 8, 0.0f);
         for (int j = 0; j < nk; ++j) {
             const float t = (float)j / (float)(nk - 1);
             for (size_t i = 0; i < nGeoms; ++i) {
@@ -722,9 +727,14 @@ int configure(pt_ctx *c)
                 pt_mat4 inv;
                 const pt_mat4 fwd = ptamd::buildTransformationMatrix(lerp3(a.translation, b.translation, t), lerp3(a.rotation, b.rotation, t),
                                                                      lerp3(a.scale, b.scale, t), c->motion_rotat, &inv);
-                float *dst = &kn[((size_t)j * nGeoms + i) * 24];
-                memcpy(dst, &inv, 12 * sizeof(float));
-                memcpy(dst + 12, &fwd, 12 * sizeof(float));
+                memcpy(&kn[((size_t)j * nGeoms + i) * 12], &fwd, 12 * sizeof(float));
+                pt_static_geom gk = a;
+                gk.transform = fwd;
+                const Aabb bk = prim_bounds(gk, 1.005, 1e-4);
+                for (int ax = 0; ax < 3; ++ax) {
+                    if (j == 0 || bk.lo[ax] < swept[8 * i + (size_t)ax]) swept[8 * i + (size_t)ax] = bk.lo[ax];
+                    if (j == 0 || bk.hi[ax] > swept[8 * i + 4 + (size_t)ax]) swept[8 * i + 4 + (size_t)ax] = bk.hi[ax];
+                }
             }
             const pt_camera_data &ca = c->cam;
             const pt_camera_data &cb = c->have_cam_next ? c->cam_next : c->cam;
@@ -742,6 +752,7 @@ int configure(pt_ctx *c)
         HIP_TRY(hipMalloc((void **)&c->d_knot_cam, kc.size() * sizeof(float)));
         if (!kn.empty()) HIP_TRY(hipMemcpy(c->d_knots, kn.data(), kn.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_knot_cam, kc.data(), kc.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (!swept.empty()) HIP_TRY(hipMemcpy(c->d_box_world, swept.data(), swept.size() * sizeof(float), hipMemcpyHostToDevice));
         k.knots = c->d_knots;
         k.knot_cam = c->d_knot_cam;
         k.nknots = nk;
@@ -858,7 +869,9 @@ int configure(pt_ctx *c)
     cfg.nee = k.nlights > 0 ? 1 : 0;             // no lights: nothing to sample, the plain kernels are exact
     // the scattering kernels only when some material that can hold a medium asks for it: else the plain kernels are exact
     cfg.motion = k.nknots > 0 ? 1 : 0;
-    if (cfg.motion) { cfg.geom = 0; cfg.workgroup = 256; cfg.nee = 0; }
+    // (per-ray shutter time: the pair queue up to 40 primitives -- pre-test against the swept boxes, exact tests in full batches with
+    // per-pair interpolated rows --, the scalar loop above that or on request)
+    if (cfg.motion) { cfg.geom = (o.geom_path == 5 || (o.geom_path == 0 && k.nG <= 40)) ? 4 : 0; cfg.workgroup = 256; cfg.nee = 0; }
     cfg.media = 0;
     if (k.scatter)
         for (const pt_material &m : c->mats)
@@ -964,7 +977,7 @@ int configure(pt_ctx *c)
     k.span_off = nullptr;
     k.span_list = nullptr;
     const bool spans_ok = k.eye_cull && !(k.lens_radius > 0.0f) && npix / 64 <= (1 << 21);    // (host work: <= 2 M spans, a 134 Mpx tile)
-    const bool want_mask = spans_ok && cfg.geom == 4 && k.nG <= 32 && k.ntri == 0 && c->h_box_eye.size() >= (size_t)k.nG * 8;
+    const bool want_mask = spans_ok && !cfg.motion && cfg.geom == 4 && k.nG <= 32 && k.ntri == 0 && c->h_box_eye.size() >= (size_t)k.nG * 8;
     const bool want_lists = spans_ok && npix % 64 == 0 && (cfg.geom == 6 || cfg.geom == 7) && c->h_boxes.size() >= (size_t)k.nG * 6 && k.nG <= 65536;
     if (want_mask || want_lists) {
         const int nspan = (npix + 63) / 64;                  // (the last one may be short; the lists need npix % 64 == 0)

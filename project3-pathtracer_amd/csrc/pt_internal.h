@@ -112,7 +112,7 @@ struct KParams {
     const float *light_cdf;
     int ngeoms;            // geoms among the nG primitives (= nG - ntri): primitive index of triangle t = ngeoms + t
     // motion blur with a shutter time per ray (FEAT_MOTION kernels): nknots scene states at shutter times k / (nknots - 1)
-    const float *knots;    // [nknots][nG][24]: inverse rows 0..2, forward rows 0..2 of every geom at every knot
+    const float *knots;    // [nknots][nG][12]: transform rows 0..2 of every geom at every knot (the inverse is computed per ray)
     const float *knot_cam; // [nknots][12]: camera position, view, up (xyz each, padded to 4)
     int nknots;            // 0 = off
     float tan_x, tan_y;    // tan of the half field-of-view angles (the per-ray camera basis is built on the device)

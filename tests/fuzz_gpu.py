@@ -71,6 +71,8 @@ def main():
             for g in geoms[2:min(len(geoms), 24)]:          # many small emitters: the light table overflows past 16
                 if g.type != O.MESH and rng.random() < 0.8:
                     g.materialid = 4
+        if os.environ.get("PT_FUZZ_FORCE_GEOM"):
+            gopts["geom_path"] = int(os.environ["PT_FUZZ_FORCE_GEOM"])
         strip = None
         if rng.random() < 0.3 and H >= 4:
             world = int(rng.integers(2, 4))
@@ -89,7 +91,7 @@ def main():
             gba = (O.StaticGeom * len(gb))(*gb)
             cam_b = O.make_camera(W, H, eye + rng.normal(0, 0.3, 3), view + rng.normal(0, 0.05, 3), up, fovy) if rng.random() < 0.5 else None
             motion = (gba, cam_b, int(rng.integers(1, 6)))
-            gopts["geom_path"] = int(rng.choice([0, 1]))
+            gopts["geom_path"] = int(rng.choice([0, 1, 5])) if n_prims <= 100 else int(rng.choice([0, 1]))
             strip = None if rng.random() < 0.5 else strip
         sh = []
         if motion:
@@ -162,6 +164,12 @@ def main():
         else:
             ok = (np.array_equal(img.view(np.uint32), ref.view(np.uint32)) and
                   [int(x) for x in st.live_in[:depth]] == [int(x) for x in live] and int(st.shadow_rays) == sh[0])
+        if not ok and os.environ.get("PT_FUZZ_VERBOSE"):
+            d = np.abs(img - (want if strip else ref)).max(axis=2)
+            ys, xs = np.nonzero(d)
+            print(f"   {len(ys)} pixels differ; live gpu {[int(x) for x in st.live_in[:depth]]} cpu {[int(x) for x in live]}")
+            for y, x in list(zip(ys, xs))[:6]:
+                print("   px", x, y, "gpu", img[y, x], "cpu", (want if strip else ref)[y, x])
         if not ok:
             bad += 1
             print(f"MISMATCH case {case}: prims={n_prims} {W}x{H} depth={depth} iters={iters} {opts} {gopts} strip={strip} motion={motion[2] if motion else None} "

@@ -154,6 +154,7 @@ def lib():
         "o_interpolateCamera": (CameraData, [P(CameraData), P(CameraData), f]),
         "o_sliceTime": (f, [i, i]),
         "o_knotTime": (f, [i, i]),
+        "o_affineInverse": (None, [P(Mat4), P(Mat4)]),
         "o_free_obj": (None, [P(f)]),
         "o_calculateScatterAndAbsorption": (i, [P(Ray), P(f), P(ScatterProps), P(Vec3), P(Material), f, f, f]),
         "o_trace_path": (Vec3, [P(StaticGeom), i, P(Material), i, P(CameraData), P(Options), i, i, u, P(i)]),

@@ -1091,11 +1091,13 @@ def test_motion_blur_matches_oracle(pkg, slices, iters, extra):
 
 
 @pytest.mark.parametrize("segments,iters,extra", [(1, 20, {}), (4, 37, {"batch": 5, "rr_start": 2}), (7, 18, {"lens_radius": 0.3, "focal_distance": 9.0, "absorption": 1}),
-                                                  (2, 35, {"sequences": 1, "geom_path": 1})])
+                                                  (2, 35, {"sequences": 1, "geom_path": 1}), (3, 21, {"geom_path": 5, "rr_start": 1}),
+                                                  (5, 9, {"geom_path": 1, "lens_radius": 0.2, "focal_distance": 10.0})])
 def test_motion_blur_per_ray_matches_oracle(pkg, segments, iters, extra):
     """pt_options.motion_per_ray: every path draws its shutter time (third number of its camera stream) and sees matrices
     and camera vectors interpolated entry-wise between the two knots around it, at all of its bounces (FEAT_MOTION
-    kernels on the scalar path; the time is re-drawn from the stream at every bounce, nothing is stored in the ray)."""
+    kernels: the pair queue by default -- pre-test against boxes swept over the shutter interval, per-pair interpolated rows --
+    and the scalar loop; the time is re-drawn from the stream at every bounce, nothing is stored in the ray)."""
     path = os.path.join(SCENES, "sampleScene_anim.txt")
     W, H, depth = 96, 72, 6
     a, b = pkg.SceneFile(path, 1, frame=0), pkg.SceneFile(path, 1, frame=1)
@@ -1139,7 +1141,7 @@ def test_motion_blur_per_ray_camera_at_rest_and_errors(pkg):
         r.render(1, 5)
         g = r.download_image()
         st = r.stats()
-        for bad in (dict(direct_light=1), dict(scatter=1), dict(geom_path=5), dict(workgroup=512)):
+        for bad in (dict(direct_light=1), dict(scatter=1), dict(geom_path=3), dict(workgroup=512)):
             r.set_options(**bad)
             with pytest.raises(pkg.PtError):
                 r.clear_image()

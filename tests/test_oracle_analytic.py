@@ -686,17 +686,34 @@ def test_per_ray_shutter_time_is_the_time_average():
 
 
 def test_per_ray_motion_with_equal_knots_is_the_static_scene():
-    """Both knots the same scene: a + (a - a) * f = a, the third camera draw changes nothing (no lens) -> the static
-    render, bit for bit; with a lens the extra draw shifts the lens draws, so the images differ."""
+    """Both knots the same scene: the interpolated transform is the transform, its computed inverse the loader's inverse up to
+    rounding (adjugate over determinant here, GLM's general 4x4 cofactor inverse there) -- the static picture except for the odd
+    silhouette pixel; with a lens the extra draw shifts the lens draws, so the images differ."""
     sc = O.LoadedScene(os.path.join(SCENES, "sampleScene_spec.txt"), 1)
     sc.set_resolution(40, 30)
     kg = [sc.geoms, sc.geoms, sc.geoms]
     a, la = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, 5, iters=3, knot_geoms=kg)
     b, lb = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, 5, iters=3)
-    assert np.array_equal(a, b) and list(la) == list(lb)
+    assert (np.abs(a - b).max(axis=2) > 1e-4).mean() < 0.03 and abs(int(la.sum()) - int(lb.sum())) <= 0.01 * int(lb.sum())
     a2, _ = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, 5, iters=3, knot_geoms=kg, lens_radius=0.2, focal_distance=8.0)
     b2, _ = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, 5, iters=3, lens_radius=0.2, focal_distance=8.0)
     assert not np.array_equal(a2, b2)
+
+
+def test_affine_inverse():
+    """o_affineInverse against numpy on random TRS transforms, and against the loader's own inverse."""
+    L = O.lib()
+    rng = np.random.default_rng(2)
+    for _ in range(50):
+        g = O.make_geom(O.CUBE, 0, rng.uniform(-5, 5, 3), rng.uniform(-3, 3, 3), rng.uniform(0.2, 6, 3))
+        out = O.Mat4()
+        L.o_affineInverse(C.byref(g.transform), C.byref(out))
+        m = np.array([[getattr(getattr(g.transform, r), c) for c in "xyzw"] for r in "xyzw"], dtype=np.float64)
+        want = np.linalg.inv(m)
+        got = np.array([[getattr(getattr(out, r), c) for c in "xyzw"] for r in "xyzw"], dtype=np.float64)
+        assert np.allclose(got, want, rtol=2e-5, atol=2e-6)
+        glm = np.array([[getattr(getattr(g.inverseTransform, r), c) for c in "xyzw"] for r in "xyzw"], dtype=np.float64)
+        assert np.allclose(got[:3], glm[:3], rtol=2e-5, atol=2e-6)
 
 
 def test_per_ray_motion_rejects_unsupported_combinations():
