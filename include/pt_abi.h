@@ -128,8 +128,8 @@ typedef struct pt_options {
                              of `slices` + 1 knot states around it, with their inverses computed from them -- exact for
                              translations, a chord approximation of
                              rotations that tightens with `slices`.  Runs on the pair queue (up to 40 primitives, or geom_path 5:
-                             pre-test against boxes swept over the shutter interval) and on the scalar loop (geom_path 1);
-                             excludes meshes, direct lighting and scattering */
+                             pre-test against boxes swept over the shutter interval) and on the scalar loop (geom_path 1), with
+                             direct lighting (lights sampled where they are at the ray's time) and scattering; excludes meshes */
 } pt_options;
 
 typedef struct pt_stats {

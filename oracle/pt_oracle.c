@@ -926,7 +926,9 @@ static o_vec3 trace_path(const o_staticGeom *geoms, int nG, const tri_table *tt,
                 if (hs == lprim && fabsf(ht - dist) <= tol) {
                     const o_material *lm = &mats[lg->materialid];
                     float G = (cx * cy) / d2;
-                    float wgt = (G * (lt->area[j] * (float)lt->n)) * 0.318309886f;
+                    /* (per-ray motion blur: the light's area at the path's time) */
+                    const float larea = (mk && lt->tri_count[j] == 0) ? o_lightArea(lg) : lt->area[j];
+                    float wgt = (G * (larea * (float)lt->n)) * 0.318309886f;
                     o_vec3 c = mul3(mul3(T, m->color), scale3(lm->emittance, lm->color));
                     L = add3(L, scale3(wgt, c));
                 }
@@ -1035,7 +1037,7 @@ static int motion_mode(const o_extras *ex, const o_options *opt, const o_staticG
 {
     if (!ex || ex->n_knots == 0) return 0;
     if (ex->n_knots < 2 || !ex->knot_geoms) return -7;
-    if (ex->n_slices > 0 || ex->n_meshes > 0 || opt->direct_light || opt->scatter) return -7;
+    if (ex->n_slices > 0 || ex->n_meshes > 0) return -7;
     for (int i = 0; i < nG; i++) if (geoms[i].type == O_MESH) return -7;
     return 1;
 }

@@ -1540,6 +1540,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                         if (j > p.nlights - 1) j = p.nlights - 1;
                         const int4 lr = *reinterpret_cast<const int4 *>(p.lights + j);      // prim, tri_first, tri_count, area
                         const float larea = __int_as_float(lr.w);
+                        float larea_m = larea;                         // (FEAT_MOTION: the light's area at the path's time)
                         so = h.p + 0.0002f * nf;
                         f3 yl, nl;
                         uint32_t lmat;
@@ -1561,6 +1562,22 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                             nl = mk(LP->fwd[0], LP->fwd[1], LP->fwd[2]);
                             if (dot(nl, yl - so) > 0.0f) nl = -nl;
                             lmat = LP->material;
+                        } else if (MOTION) {
+                            // the light where it is at this path's time: rows interpolated between the knots, area from them
+                            // (getRadiuses' half-extents, the oracle's o_lightArea)
+                            lprim = (uint32_t)lr.x;
+                            const uint32_t ltype = p.prims[lprim].type;
+                            float linv[12], lfwd[12];
+                            motionRows(p, lprim, mt, linv, lfwd);
+                            sampleLight(ltype, lfwd, mk(lfwd[3], lfwd[7], lfwd[11]), u_seed * 16777216.0f, yl, nl);
+                            const f3 rad = getRadiuses(lfwd);
+                            if (ltype == 1u) {
+                                const float side1 = rad.x * rad.y * 4.0f, side2 = rad.z * rad.y * 4.0f, side3 = rad.x * rad.z * 4.0f;
+                                larea_m = 2.0f * (side1 + side2 + side3);
+                            } else {
+                                larea_m = 4.18879020478639098f * ((rad.x * rad.y + rad.x * rad.z) + rad.y * rad.z);
+                            }
+                            lmat = p.prims[lprim].material;
                         } else {
                         lprim = (uint32_t)lr.x;
                         const Prim *LP = PRIMS_IN_LDS ? &s_prims[lprim] : &p.prims[lprim];
@@ -1585,7 +1602,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                         if (cx > 0.0f && cy > 0.0f) {
                             want_shadow = true;
                             const float G = (cx * cy) / d2;
-                            const float wgt = (G * (larea * (float)p.nlights)) * 0.318309886f;
+                            const float wgt = (G * (larea_m * (float)p.nlights)) * 0.318309886f;
                             const uint32_t lm = lmat;
                             const f3 col = mk(s_mats[M_CR * p.nM + m], s_mats[M_CG * p.nM + m], s_mats[M_CB * p.nM + m]);
                             const f3 lcol = mk(s_mats[M_CR * p.nM + lm], s_mats[M_CG * p.nM + lm], s_mats[M_CB * p.nM + lm]);
@@ -1621,11 +1638,18 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                     } else if (pass_through) {
                         nd = d;
                         bias_n = -nf;
+                        f3 v;
+                        if (MOTION) {
+                            float minv[12], mfwd[12];
+                            motionRows(p, h.prim, mt, minv, mfwd);
+                            v = mulMV(minv, d, 0.0f);
+                        } else {
                         const Prim *HP = PRIMS_IN_LDS ? &s_prims[h.prim] : &p.prims[h.prim];
                         const float4 *iv = reinterpret_cast<const float4 *>(HP->inv);
                         const float4 i0 = iv[0], i1 = iv[1], i2 = iv[2];
                         const float inv[12] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x, i2.y, i2.z, i2.w};
-                        const f3 v = (HP->type == 3u) ? d : mulMV(inv, d, 0.0f);      // a triangle is tested in world space
+                        v = (HP->type == 3u) ? d : mulMV(inv, d, 0.0f);      // a triangle is tested in world space
+                        }
                         bias = 0.0002f + 1e-4f * rsqrt_rn(dot(v, v));
                     } else if (refr > 0.0f) {
                         const float ior = s_mats[M_IOR * p.nM + m];
@@ -1689,8 +1713,15 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
             const uint64_t wmask = __ballot(want_shadow);
             if (wmask != 0ull) {                              // wave-uniform
                 shadow_count += (uint32_t)__popcll(wmask);
-                const Hit hs = nearestHit<GEOM, false>(p, s_prims, (GEOM == GEOM_PAIR) ? s_nodes + 2 * p.nG : s_nodes, wq, so, sd,
-                                                       want_shadow, (uint32_t)lane);
+                Hit hs;
+                if (MOTION && GEOM == GEOM_PAIR) {
+                    hs = nearestHit<GEOM, false, true>(p, s_prims, s_nodes + 2 * p.nG, wq, so, sd, want_shadow, (uint32_t)lane, 0xFFFFFFFFu, mt);
+                } else if (MOTION) {
+                    hs.any = false; hs.material = 0; hs.prim = 0; hs.t = 0.0f; hs.p = mk(0, 0, 0); hs.n = mk(0, 0, 0);
+                    if (want_shadow) hs = nearestHitMotion(p, so, sd, mt);
+                } else {
+                    hs = nearestHit<GEOM, false>(p, s_prims, (GEOM == GEOM_PAIR) ? s_nodes + 2 * p.nG : s_nodes, wq, so, sd, want_shadow, (uint32_t)lane);
+                }
                 if (want_shadow && hs.any && hs.prim == lprim) {
                     const float tol = 1e-3f * ((ldist > 1.0f) ? ldist : 1.0f);
                     if (fabsf(hs.t - ldist) <= tol) L = L + Ld;          // the sampled point itself is what the ray reached
@@ -1829,11 +1860,15 @@ static const void *bounce_fn_geom(bool first, int compact, int feat)
 {
     if (feat != 0) {
         if (compact != 1) return nullptr;
-        if (feat == FEAT_MOTION) {            // per-ray shutter time: the scalar and the pair path, 256-thread workgroups only
-            if constexpr ((GEOM == GEOM_SCALAR || GEOM == GEOM_PAIR) && WG == 256) return bounce_fn_feat<256, GEOM, FEAT_MOTION>(first);
+        if ((feat & FEAT_MOTION) != 0) {      // per-ray shutter time: the scalar and the pair path, 256-thread workgroups only
+            if constexpr ((GEOM == GEOM_SCALAR || GEOM == GEOM_PAIR) && WG == 256) {
+                if (feat == FEAT_MOTION) return bounce_fn_feat<256, GEOM, FEAT_MOTION>(first);
+                if (feat == (FEAT_MOTION | FEAT_NEE)) return bounce_fn_feat<256, GEOM, FEAT_MOTION | FEAT_NEE>(first);
+                if (feat == (FEAT_MOTION | FEAT_MEDIA)) return bounce_fn_feat<256, GEOM, FEAT_MOTION | FEAT_MEDIA>(first);
+                return bounce_fn_feat<256, GEOM, FEAT_MOTION | FEAT_NEE | FEAT_MEDIA>(first);
+            }
             return nullptr;
         }
-        if ((feat & FEAT_MOTION) != 0) return nullptr;
         if (feat == FEAT_NEE) return bounce_fn_feat<WG, GEOM, FEAT_NEE>(first);
         if (WG == 256 || WG == 512) {
             if (feat == FEAT_MEDIA) return bounce_fn_feat<(WG == 256 || WG == 512) ? WG : 256, GEOM, FEAT_MEDIA>(first);

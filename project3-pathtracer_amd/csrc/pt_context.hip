@@ -709,7 +709,6 @@ int configure(pt_ctx *c)
         if (nT > 0) return fail(PT_ERR_INVALID, "motion_per_ray: triangle meshes need the slice scheme (motion_per_ray = 0)");
         for (const pt_static_geom &g : c->geoms)
             if (g.type == PT_MESH) return fail(PT_ERR_INVALID, "motion_per_ray: MESH objects need the slice scheme (motion_per_ray = 0)");
-        if (o.direct_light || o.scatter) return fail(PT_ERR_INVALID, "motion_per_ray excludes direct_light and scatter (use the slice scheme)");
         if (o.compaction != 1) return fail(PT_ERR_INVALID, "motion_per_ray needs compaction 1 (got %d)", o.compaction);
         if (!(o.geom_path == 0 || o.geom_path == 1 || o.geom_path == 5))
             return fail(PT_ERR_INVALID, "motion_per_ray runs on the scalar and the pair-queue geometry paths (geom_path 0, 1 or 5, got %d)", o.geom_path);
@@ -871,7 +870,7 @@ int configure(pt_ctx *c)
     cfg.motion = k.nknots > 0 ? 1 : 0;
     // (per-ray shutter time: the pair queue up to 40 primitives -- pre-test against the swept boxes, exact tests in full batches with
     // per-pair interpolated rows --, the scalar loop above that or on request)
-    if (cfg.motion) { cfg.geom = (o.geom_path == 5 || (o.geom_path == 0 && k.nG <= 40)) ? 4 : 0; cfg.workgroup = 256; cfg.nee = 0; }
+    if (cfg.motion) { cfg.geom = (o.geom_path == 5 || (o.geom_path == 0 && k.nG <= 40)) ? 4 : 0; cfg.workgroup = 256; }
     cfg.media = 0;
     if (k.scatter)
         for (const pt_material &m : c->mats)

@@ -83,7 +83,7 @@ def main():
         ma = (O.Material * len(mats))(*mats)
         cam = O.make_camera(W, H, eye, view, up, fovy)
         motion = None
-        if meshes is None and not opts.get("direct_light") and not opts.get("scatter") and rng.random() < 0.15:
+        if meshes is None and rng.random() < 0.15:
             # motion blur with a shutter time per ray: a second frame (every object moved, turned and rescaled a little,
             # sometimes the camera too), 1..5 linear segments; scalar geometry path
             gb = [O.make_geom(g.type, g.materialid, np.array(g.translation.tup()) + rng.normal(0, 0.4, 3),

@@ -1092,7 +1092,8 @@ def test_motion_blur_matches_oracle(pkg, slices, iters, extra):
 
 @pytest.mark.parametrize("segments,iters,extra", [(1, 20, {}), (4, 37, {"batch": 5, "rr_start": 2}), (7, 18, {"lens_radius": 0.3, "focal_distance": 9.0, "absorption": 1}),
                                                   (2, 35, {"sequences": 1, "geom_path": 1}), (3, 21, {"geom_path": 5, "rr_start": 1}),
-                                                  (5, 9, {"geom_path": 1, "lens_radius": 0.2, "focal_distance": 10.0})])
+                                                  (5, 9, {"geom_path": 1, "lens_radius": 0.2, "focal_distance": 10.0}),
+                                                  (2, 19, {"direct_light": 1}), (3, 17, {"direct_light": 1, "geom_path": 1, "rr_start": 2})])
 def test_motion_blur_per_ray_matches_oracle(pkg, segments, iters, extra):
     """pt_options.motion_per_ray: every path draws its shutter time (third number of its camera stream) and sees matrices
     and camera vectors interpolated entry-wise between the two knots around it, at all of its bounces (FEAT_MOTION
@@ -1119,12 +1120,39 @@ def test_motion_blur_per_ray_matches_oracle(pkg, segments, iters, extra):
     oa, ob = O.LoadedScene(path, 1, frame=0), O.LoadedScene(path, 1, frame=1)
     oa.set_resolution(W, H)
     kg, kc = O.motion_knots(oa.geoms, ob.geoms, oa.n_objects, oa.camera, ob.camera, segments, O.ROTAT_DEGREES)
-    okw = {k: v for k, v in extra.items() if k in ("rr_start", "lens_radius", "focal_distance", "absorption")}
-    c, lc = O.render(oa.geoms, oa.n_objects, oa.mats, oa.n_materials, oa.camera, depth, iters=iters, knot_geoms=kg, knot_cams=kc, **okw)
+    okw = {k: v for k, v in extra.items() if k in ("rr_start", "lens_radius", "focal_distance", "absorption", "direct_light")}
+    sh = []
+    c, lc = O.render(oa.geoms, oa.n_objects, oa.mats, oa.n_materials, oa.camera, depth, iters=iters, knot_geoms=kg, knot_cams=kc, shadow_out=sh, **okw)
     check(g, c, [int(x) for x in st.live_in[:depth]], [int(x) for x in lc], f"per-ray motion blur, {segments} segment(s)")
-    assert int(st.iterations) == iters
+    assert int(st.iterations) == iters and int(st.shadow_rays) == sh[0]
     c0, _ = O.render(oa.geoms, oa.n_objects, oa.mats, oa.n_materials, oa.camera, depth, iters=3, **okw)
     assert np.array_equal(static, c0) and not np.array_equal(g, c0)
+
+
+@pytest.mark.parametrize("geom_path", [0, 1])
+def test_motion_blur_per_ray_with_scattering(pkg, geom_path):
+    """A shutter time per ray through the scattering media of sss_blobs.txt (every object shifted, turned and rescaled a
+    little between the two frames): random walk, index-matched pass-through and its offset at the ray's own time."""
+    path = os.path.join(SCENES, "sss_blobs.txt")
+    W, H, depth, iters = 72, 72, 10, 3
+    sc = O.LoadedScene(path, 1)
+    sc.set_resolution(W, H)
+    rng = np.random.default_rng(12)
+    gb = [O.make_geom(g.type, g.materialid, np.array(g.translation.tup()) + rng.normal(0, 0.15, 3), np.array(g.rotation.tup()) + rng.normal(0, 5.0, 3),
+                      np.array(g.scale.tup()) * rng.uniform(0.9, 1.1, 3), O.ROTAT_DEGREES) for g in list(sc.geoms)[:sc.n_objects]]
+    gba = (O.StaticGeom * len(gb))(*gb)
+    kg, _ = O.motion_knots(sc.geoms, gba, sc.n_objects, sc.camera, None, 2, O.ROTAT_DEGREES)
+    c, lc = O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, depth, iters=iters, knot_geoms=kg, scatter=1, direct_light=1)
+    with pkg.Renderer(0) as r:
+        r.set_options(depth=depth, motion_per_ray=1, scatter=1, direct_light=1, geom_path=geom_path)
+        r.set_scene(C.cast(sc.geoms, C.POINTER(pkg.StaticGeom)), sc.n_objects, C.cast(sc.mats, C.POINTER(pkg.Material)), sc.n_materials)
+        r.set_camera(pkg.CameraData.from_buffer_copy(sc.camera))
+        r.set_motion(C.cast(gba, C.POINTER(pkg.StaticGeom)), None, 2, pkg.ROTAT_DEGREES)
+        r.clear_image()
+        r.render(1, iters)
+        g = r.download_image()
+        st = r.stats()
+    check(g, c, [int(x) for x in st.live_in[:depth]], [int(x) for x in lc], f"per-ray motion blur with scattering + direct lighting, geom_path={geom_path}")
 
 
 def test_motion_blur_per_ray_camera_at_rest_and_errors(pkg):
@@ -1141,7 +1169,7 @@ def test_motion_blur_per_ray_camera_at_rest_and_errors(pkg):
         r.render(1, 5)
         g = r.download_image()
         st = r.stats()
-        for bad in (dict(direct_light=1), dict(scatter=1), dict(geom_path=3), dict(workgroup=512)):
+        for bad in (dict(geom_path=3), dict(workgroup=512)):
             r.set_options(**bad)
             with pytest.raises(pkg.PtError):
                 r.clear_image()

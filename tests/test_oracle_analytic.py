@@ -720,6 +720,6 @@ def test_per_ray_motion_rejects_unsupported_combinations():
     sc = O.LoadedScene(os.path.join(SCENES, "sampleScene_spec.txt"), 1)
     sc.set_resolution(16, 12)
     kg = [sc.geoms, sc.geoms]
-    for kw in (dict(direct_light=1), dict(scatter=1), dict(slice_geoms=[sc.geoms, sc.geoms])):
+    for kw in (dict(slice_geoms=[sc.geoms, sc.geoms]), dict(meshes={0: np.zeros((1, 9), np.float32)})):
         with pytest.raises(RuntimeError):
             O.render(sc.geoms, sc.n_objects, sc.mats, sc.n_materials, sc.camera, 3, knot_geoms=kg, **kw)
