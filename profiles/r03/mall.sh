@@ -1,6 +1,6 @@
 O=gpurun_out/${1:-r03z}
 mkdir -p $O
-for i in 1 2; do for l in lib_nont; do for cfg in "1 4" "2 4" "2 2" "4 2" "4 4" "16 2"; do set -- $cfg
+for i in 1 2; do for l in lib; do for cfg in "1 4" "2 4" "2 2" "4 2" "4 4" "16 2"; do set -- $cfg
   PT_LIBPTAMD=$GRAFT_REPO_ROOT/project3-pathtracer_amd/$l/libptamd.so python bench.py --no-cpu-baseline --batch $1 --sequences $2 > $O/${l}_b$1_s$2_$i.json 2>>$O/err.txt
 done; done; done
 python - <<PY
