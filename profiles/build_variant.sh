@@ -6,7 +6,7 @@ set -e
 NAME=$1; UNITS=$2; EXTRA=$3
 cd "$(dirname "$0")/../project3-pathtracer_amd/csrc"
 mkdir -p ../lib_$NAME
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize $EXTRA"
+FLAGS="--offload-arch=${VARIANT_ARCH:-gfx950} -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize $EXTRA"
 REPL=""
 for u in $UNITS; do
   case $u in
@@ -22,6 +22,6 @@ done
 wait
 OBJS=""
 for f in ../lib/*.o; do b=$(basename $f); if echo " $REPL " | grep -q " $b "; then OBJS="$OBJS ../lib_$NAME/$b"; else OBJS="$OBJS $f"; fi; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../lib_$NAME/libptamd.so $OBJS
+/opt/rocm/bin/hipcc --offload-arch=${VARIANT_ARCH:-gfx950} -shared -o ../lib_$NAME/libptamd.so $OBJS
 rm -f ../lib_$NAME/*.o
 ls -la ../lib_$NAME/libptamd.so
