@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--no-compaction", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="iterations in flight per launch sequence (0 = library default)")
     ap.add_argument("--sequences", type=int, default=0, help="launch sequences in flight (0 = library default 2)")
+    ap.add_argument("--resident", type=int, default=0, choices=[-1, 0, 1],
+                    help="later bounces as ONE launch with the paths resident in registers: 1 on, -1 off, 0 = library default")
     ap.add_argument("--dist-timeout", type=float, default=600.0,
                     help="N > 1: seconds a rank waits for the others before giving up (a fresh box pages torch in for a minute or two)")
     ap.add_argument("--compaction", type=int, default=1, help="1 per-wave sharded (default), 2 workgroup scan, 0 off")
@@ -209,7 +211,8 @@ def main():
                   compaction=0 if args.no_compaction else args.compaction, batch=args.batch, use_graph=0 if args.no_graph else 1,
                   row_begin=r0 if (world > 1 and not strips) else 0, row_end=r1 if (world > 1 and not strips) else 0,
                   strip_rows=sharding.STRIP_ROWS if strips else 0, strip_world=world if strips else 0,
-                  strip_rank=rank if strips else 0, direct_light=1 if args.direct_light else 0, sequences=args.sequences)
+                  strip_rank=rank if strips else 0, direct_light=1 if args.direct_light else 0, sequences=args.sequences,
+                  resident=args.resident)
     r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
     r.set_camera(sc.camera)
     r.bind_image(fb.data_ptr())
@@ -357,7 +360,8 @@ def main():
         # the render stream (the library's own event pair around the pt_render call; it spans both sequences and includes
         # the batches' accumulate and bookkeeping kernels, ~4 %: conservative).  A launch's own duration overlaps its
         # neighbour's; `kernel_alone` below is the per-launch figure with one sequence (eager launches, one event pair each).
-        lib_batch = args.batch or 16
+        li = r.launch_info()                   # what the library actually chose (not the options, not the environment)
+        lib_batch = li.batch
         nb_timed = (args.steps + lib_batch - 1) // lib_batch
         timed_batches = [args.steps // nb_timed + (1 if j < args.steps % nb_timed else 0) for j in range(nb_timed)]
         launches_timed = int(st.bounce_launches)      # one launch carries one bounce of one batch (the camera kernel: bounces 0 and 1)
@@ -415,7 +419,8 @@ def main():
                 "baseline_config": args.config, "scene": args.scene, "width": W, "height": Hfull, "depth": args.depth, "spp": args.steps,
                 "rotat_units": args.rotat, "primitives": sc.n_objects, "materials": sc.n_materials,
                 "compaction": 0 if args.no_compaction else args.compaction, "iteration_batch": lib_batch, "timed_batches": timed_batches,
-                "launch_sequences_in_flight": args.sequences or int(os.environ.get("PT_SEQUENCES", "2")),
+                "launch_sequences_in_flight": li.sequences, "geom_path": li.geom_path, "workgroup": li.workgroup, "grid": li.grid,
+                "resident_paths": bool(li.resident), "bounce_launches_per_batch": li.launches_per_batch,
                 "hip_graph": not args.no_graph, "direct_light": bool(args.direct_light),
                 "parallelism": (f"pixel-strips x{world}" if strips else f"pixel-bands x{world}") +
                                (", 1 RCCL gather of the rendered frame behind the timed steps" if world > 1 else ""),

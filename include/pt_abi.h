@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 1
+#define PT_ABI_VERSION 2     /* 2: pt_options grew (sequences, motion_per_ray, resident); pt_abi_version / pt_options_size added */
 #define PT_MAX_DEPTH 64
 #define PT_MAX_SEQUENCES 4   /* launch sequences in flight per context (pt_options.sequences) */
 
@@ -130,6 +130,11 @@ typedef struct pt_options {
                              rotations that tightens with `slices`.  Runs on the pair queue (up to 40 primitives, or geom_path 5:
                              pre-test against boxes swept over the shutter interval) and on the scalar loop (geom_path 1), with
                              direct lighting (lights sampled where they are at the ray's time) and scattering; excludes meshes */
+    int resident;         /* the later bounces of a batch as ONE launch with the paths resident in registers (a wave keeps the
+                             paths that go on, refills the lanes of those that ended from the camera launch's ray pool): 1 = on
+                             where a kernel exists for the launch shape (pair queue and batched walks, i.e. geom_path 0 / 5 / 7 / 8,
+                             without direct_light / scatter / motion_per_ray, depth >= 3), -1 = off (one launch per bounce),
+                             0 = library choice (default).  The image does not depend on it */
 } pt_options;
 
 typedef struct pt_stats {
@@ -154,6 +159,11 @@ int  pt_create(int device, pt_ctx **out);             /* persistent device conte
 void pt_destroy(pt_ctx *ctx);
 const char *pt_last_error(void);
 const char *pt_version(void);
+/* What the loaded library was built against: a client compares them with its own PT_ABI_VERSION and sizeof(pt_options)
+ * before the first pt_set_options (the struct travels by pointer, without a size: a client built against an older header
+ * would hand over a shorter one).  The Python binding and the shim check both when they load the library. */
+int  pt_abi_version(void);
+size_t pt_options_size(void);
 
 /* ---- inputs (replaces ref: src/raytraceKernel.cu:123-146) ---- */
 void pt_default_options(pt_options *opt);
@@ -213,9 +223,26 @@ int  pt_render_iteration(pt_ctx *ctx, pt_uchar4 *device_pbo_or_null, float *host
 /* ---- measurement ---- */
 int  pt_get_stats(pt_ctx *ctx, pt_stats *out);        /* synchronizes the render stream */
 int  pt_reset_stats(pt_ctx *ctx);
+/* The launch shape the library chose for the current scene / camera / options (configures the context if needed):
+ * what bench.py reports instead of guessing from the options and the environment. */
+typedef struct pt_launch_info {
+    int geom_path;        /* pt_options.geom_path numbering (1..8) of the path actually used */
+    int workgroup;        /* threads per workgroup */
+    int grid;             /* workgroups per bounce launch (persistent grid) */
+    int batch;            /* iterations in flight per launch sequence */
+    int sequences;        /* launch sequences in flight */
+    int resident;         /* 1 = the later bounces run as ONE launch with the paths resident in registers */
+    int refill_min;       /*   free lanes that trigger a wave's refill there */
+    int launches_per_batch;   /* bounce-kernel launches per batch: depth, or 2 with resident paths */
+    int lds_bytes;        /* dynamic LDS per workgroup of the later-bounce kernel */
+    int reserved[7];
+} pt_launch_info;
+int  pt_get_launch_info(pt_ctx *ctx, pt_launch_info *out);
+
 /* Like pt_render (eager launches), but every per-bounce kernel launch is bracketed by its own pair of HIP
  * events on the render stream; bounce_ms_out[b] (depth entries) receives the summed duration of bounce b's
- * launches over the rendered iterations.  Synchronous.  For roofline accounting, not for throughput. */
+ * launches over the rendered iterations (resident paths: [0] the camera launch, [1] the one launch of all later bounces, the
+ * rest 0).  Synchronous.  For roofline accounting, not for throughput. */
 int  pt_render_profiled(pt_ctx *ctx, int iter_first, int iter_count, double *bounce_ms_out);
 /* Device self-test: the kernels' short correctly-rounded sqrt / reciprocal / reciprocal-sqrt sequences against
  * the compiler's general ones for ALL 2^32 fp32 inputs.  mismatches_out[0..2] must come back 0. */

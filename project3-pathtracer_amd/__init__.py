@@ -24,6 +24,7 @@ ROOT = os.path.dirname(PKG_DIR)
 HEADER_PATH = os.path.join(ROOT, "include", "pt_abi.h")
 
 PT_MAX_DEPTH = 64
+PT_ABI_VERSION = 2          # include/pt_abi.h; checked against the loaded library in lib()
 PT_OK = 0
 SPHERE, CUBE, MESH = 0, 1, 2
 ROTAT_RADIANS, ROTAT_DEGREES = 0, 1
@@ -66,13 +67,19 @@ class Options(C.Structure):
                 ("workgroup", C.c_int), ("geom_path", C.c_int), ("row_begin", C.c_int), ("row_end", C.c_int),
                 ("use_graph", C.c_int), ("batch", C.c_int), ("direct_light", C.c_int), ("absorption", C.c_int), ("strip_rows", C.c_int), ("strip_world", C.c_int),
                 ("strip_rank", C.c_int), ("scatter", C.c_int), ("lens_radius", C.c_float), ("focal_distance", C.c_float),
-                ("sequences", C.c_int), ("motion_per_ray", C.c_int)]
+                ("sequences", C.c_int), ("motion_per_ray", C.c_int), ("resident", C.c_int)]
 
 
 class Stats(C.Structure):
     _fields_ = [("iterations", C.c_ulonglong), ("ray_bounces", C.c_ulonglong),
                 ("live_in", C.c_ulonglong * PT_MAX_DEPTH), ("gpu_ms", C.c_double),
                 ("bounce_launches", C.c_ulonglong), ("shadow_rays", C.c_ulonglong)]
+
+
+class LaunchInfo(C.Structure):      # pt_launch_info
+    _fields_ = [("geom_path", C.c_int), ("workgroup", C.c_int), ("grid", C.c_int), ("batch", C.c_int), ("sequences", C.c_int),
+                ("resident", C.c_int), ("refill_min", C.c_int), ("launches_per_batch", C.c_int), ("lds_bytes", C.c_int),
+                ("reserved", C.c_int * 7)]
 
 
 class Mesh(C.Structure):            # pt_mesh: triangles of one MESH geom, object space, 9 floats each
@@ -119,6 +126,9 @@ def lib():
         "pt_destroy": (None, [vp]),
         "pt_last_error": (cp, []),
         "pt_version": (cp, []),
+        "pt_get_launch_info": (i, [vp, P(LaunchInfo)]),
+        "pt_abi_version": (i, []),
+        "pt_options_size": (sz, []),
         "pt_default_options": (None, [P(Options)]),
         "pt_set_options": (i, [vp, P(Options)]),
         "pt_get_options": (i, [vp, P(Options)]),
@@ -177,6 +187,10 @@ def lib():
         fn.restype = res
         fn.argtypes = args
     L._declared = sorted(sig)
+    # pt_options travels by pointer without a size: refuse a library built against another layout
+    if L.pt_abi_version() != PT_ABI_VERSION or L.pt_options_size() != C.sizeof(Options):
+        raise PtError(f"{LIB_PATH}: ABI {L.pt_abi_version()} / pt_options of {L.pt_options_size()} B, this binding expects "
+                      f"ABI {PT_ABI_VERSION} / {C.sizeof(Options)} B -- rebuild the library (make -C csrc)")
     _lib = L
     return L
 
@@ -314,6 +328,12 @@ class Renderer:
         s = Stats()
         _check(self.L.pt_get_stats(self.h, C.byref(s)), "pt_get_stats")
         return s
+
+    def launch_info(self):
+        """The launch shape the library chose (geometry path, workgroup, grid, batch, sequences, resident paths)."""
+        li = LaunchInfo()
+        _check(self.L.pt_get_launch_info(self.h, C.byref(li)), "pt_get_launch_info")
+        return li
 
     def render_profiled(self, iter_first, iter_count):
         """Per-bounce kernel time (ms, summed over the iterations), one HIP event pair per launch."""

@@ -1181,11 +1181,25 @@ __device__ __forceinline__ uint32_t globalPixel(const KParams &p, uint32_t pl)
 // instruction count (measured: the scattering code alone costs the plain kernel 1.1 % when compiled in):
 // bit 0 = NEE (pt_options.direct_light), bit 1 = MEDIA (pt_options.scatter: subsurface random walk).
 // bit 2 = MOTION (pt_options.motion_per_ray: a shutter time per ray; scalar geometry path only).
-enum { FEAT_NEE = 1, FEAT_MEDIA = 2, FEAT_MOTION = 4 };
+// bit 3 = RESIDENT (pt_options.resident, round 4): ONE launch for all the later bounces.  `bounce` is the first bounce the
+//         launch traces (1: the camera kernel's survivors); a wave takes its rays from that bounce's pool, and a path that goes on
+//         stays in its lane's registers -- origin, direction, throughput, pixel word and its own bounce number -- for the next
+//         trip of the wave's loop instead of travelling through the pools: no reservation atomic, no pool write, no pool read
+//         for bounces 2 .. depth - 1, and depth - 2 launches (ramp, LDS staging, tail) fewer per batch.  Lanes whose path has
+//         ended are refilled from the pool (KParams::refill_min free lanes trigger it).  Nothing depends on which lane or trip
+//         traces a path: every RNG stream is keyed on (global pixel, iteration, bounce) -- the stream keys of all bounces sit in an
+//         LDS table --, a path still writes its one radiance sample when it ends, and the per-bounce live counts come from an
+//         LDS histogram of the bounce each path ended at.
+enum { FEAT_NEE = 1, FEAT_MEDIA = 2, FEAT_MOTION = 4, FEAT_RESIDENT = 8 };
 template <int WG, bool FIRST, int GEOM, int COMPACT, int FEAT = 0>
-__global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce(const KParams p, const int bounce)
+// (the resident-path instances of the batched walks are held to 80 VGPRs -- 6 waves per SIMD, three 512-thread workgroups per CU,
+// what the launch-per-bounce kernels reach unasked)
+__global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G)) ? 6
+                                 : ((WG <= 256 && (FEAT & ~FEAT_RESIDENT) == 0) ? 5 : 1)) void k_bounce(const KParams p, const int bounce)
 {
     constexpr bool NEE = (FEAT & FEAT_NEE) != 0, MEDIA = (FEAT & FEAT_MEDIA) != 0, MOTION = (FEAT & FEAT_MOTION) != 0;
+    constexpr bool RESIDENT = (FEAT & FEAT_RESIDENT) != 0;
+    static_assert(!RESIDENT || (!FIRST && COMPACT == 1 && !NEE), "resident paths: later bounces, compaction 1, no light sampling");
     constexpr int NW = WG / 64;
     constexpr bool PRIMS_IN_LDS = (GEOM == GEOM_LDS || GEOM == GEOM_QUEUE || GEOM == GEOM_PAIR);   // GEOM_BVH gathers records from global memory (L1/L2)
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
@@ -1205,6 +1219,9 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
     float *s_mats = reinterpret_cast<float *>(s_queue + queue_bytes);
     const int mat_words = (p.nM * M_PLANES + 3) & ~3;
     uint32_t *s_scan = reinterpret_cast<uint32_t *>(s_mats + mat_words);   // [2][NW] wave totals, [2] bases
+    // RESIDENT: stream keys of every (bounce, iteration slot) and the histogram of the bounce each path ended at
+    uint32_t *s_keys = s_scan + ((2 * NW + 2 + 3) & ~3);                   // [depth][MAXSLOT]
+    uint32_t *s_term = s_keys + (RESIDENT ? p.depth * MAXSLOT : 0);        // [depth]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: chunk bookkeeping runs on the scalar unit
@@ -1267,6 +1284,11 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
         s_key[tid] = stream_key(iter + (uint32_t)tid, (uint32_t)bounce + 1u, p.seed);
         if (FIRST || MOTION) s_key_cam[tid] = stream_key(iter + (uint32_t)tid, 0u, p.seed);
     }
+    if (RESIDENT) {
+        for (int k = tid; k < p.depth * MAXSLOT; k += WG)
+            s_keys[k] = stream_key(iter + (uint32_t)(k & (MAXSLOT - 1)), (uint32_t)(k / MAXSLOT) + 1u, p.seed);
+        if (tid < p.depth) s_term[tid] = 0u;
+    }
     const uint32_t npix = (uint32_t)p.npix;
 
     // Input: the live rays of this bounce sit in up to NSHARD dense segments of the pool (one per reservation
@@ -1309,7 +1331,78 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
         return chunk < total_chunks && idx < cu.nseg;
     };
     Cursor cur = {0u, 0u, (uint32_t)__builtin_amdgcn_readfirstlane((int)s_segn[0])};
-    for (uint32_t R = blockIdx.x; R * NW < total_chunks; R += gridDim.x, ++round) {     // workgroup-uniform trip count
+    // RESIDENT: chunks are DRAWN, not dealt.  With equal shares a launch's workgroups do not finish together -- the SIMDs favour
+    // their oldest waves: lifetimes of 1.10 .. 2.10 ms in a 2.10 ms launch, profiles/r04/workgroup_lifetimes.txt -- and every CU
+    // runs out the last third of the launch with ever fewer waves.  NSHARD draw counters (IterState::draw, zeroed by
+    // k_iter_begin), counter k over chunks [k*Q, (k+1)*Q): a wave draws from the counter it starts with until that range is
+    // used up, then from the next one that is not (one 32-lane read of all counters), and ends when none is left -- so the
+    // waves of a launch run out of pool together.  The next draw is in flight while the current chunk is consumed (lane 0's
+    // returning atomic, read a trip or more later).  What a wave keeps between trips is three scalars: the next pool slot to
+    // hand out, the end of the chunk in hand, and a word of flags (its counter, "a draw is in flight", "the pool has more");
+    // chunk -> (segment, offset) goes through two 32-entry LDS tables (the batched walk has no scalar registers to spare).
+    __shared__ uint32_t s_cfirst[NSHARD];            // first chunk of each segment (chunks are numbered segment by segment)
+    __shared__ uint32_t s_draw[2];                   // chunks in the pool, chunks per draw counter
+    if (RESIDENT) {
+        if (tid < NSHARD) {
+            uint32_t cf = 0;
+            for (int k = 0; k < tid; ++k) cf += (s_segn[k] + 63u) >> 6;
+            s_cfirst[tid] = cf;
+        }
+        if (tid == 0) { s_draw[0] = total_chunks; s_draw[1] = (total_chunks + (uint32_t)NSHARD - 1u) / (uint32_t)NSHARD; }
+        __syncthreads();
+    }
+    uint32_t cpos = 0u, cend = 0u;                   // RESIDENT: next pool slot to hand out / end of the chunk in hand (wave-uniform)
+    enum : uint32_t { WF_SHARD = 31u, WF_DRAWN = 32u, WF_MORE = 64u };
+    uint32_t wflags = (gwave & WF_SHARD) | WF_MORE;  // RESIDENT, wave-uniform
+    uint32_t drawn = 0u;                             // RESIDENT, lane 0: the draw in flight
+    // (the batched walk sits at its register limit -- 80 VGPRs: three 512-thread workgroups per CU -- and has no register for a
+    // draw in flight across the nearest-hit search: it draws when it needs a chunk, every third trip or so, and the other waves
+    // cover that round trip)
+    constexpr bool DRAW_AHEAD = true;
+    // the next chunk of the pool for this wave: sets cpos / cend; false = the pool is used up
+    auto draw_chunk = [&]() -> bool {
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_draw[0]);
+        const uint32_t Q = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_draw[1]);
+        // chunks of counter `lane`'s range (lanes 0 .. NSHARD - 1)
+        const uint32_t lo_l = (uint32_t)lane * Q, hi_l = (lo_l + Q < total) ? lo_l + Q : total;
+        const uint32_t size_l = (lane < NSHARD && hi_l > lo_l) ? hi_l - lo_l : 0u;
+        for (;;) {
+            const uint32_t dshard = wflags & WF_SHARD;
+            if ((wflags & WF_DRAWN) == 0u && lane == 0) drawn = atomicAdd(&st->draw[dshard * (uint32_t)CNT_STRIDE], 1u);
+            const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)drawn);
+            wflags &= ~WF_DRAWN;
+            const uint32_t size = (uint32_t)__builtin_amdgcn_readlane((int)size_l, (int)dshard);
+            if (idx < size) {
+                const uint32_t chunk = dshard * Q + idx;
+                if (DRAW_AHEAD) {
+                    if (lane == 0) drawn = atomicAdd(&st->draw[dshard * (uint32_t)CNT_STRIDE], 1u);  // the next one, used a trip or more later
+                    wflags |= WF_DRAWN;
+                }
+                // chunk -> segment: the last segment that starts at or before it (an empty segment starts where the next one does)
+                const uint32_t cf = lane < NSHARD ? s_cfirst[lane] : 0xFFFFFFFFu;
+                const uint32_t sh = (uint32_t)__popcll(__ballot(cf <= chunk)) - 1u;
+                const uint32_t first = (chunk - (uint32_t)__builtin_amdgcn_readlane((int)cf, (int)sh)) * 64u;
+                const uint32_t nseg = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_segn[sh]);
+                cpos = sh * p.segcap + first;
+                cend = cpos + (nseg - first < 64u ? nseg - first : 64u);
+                return true;
+            }
+            // this range is used up: which ones are not?  (The counters only grow: a stale value can show a used-up range as
+            // open -- the draw then says so --, never an open one as used up.)
+            const uint32_t seen = lane < NSHARD ? __hip_atomic_load(&st->draw[(uint32_t)lane * (uint32_t)CNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+            const uint32_t open = (uint32_t)__ballot(seen < size_l);
+            if (open == 0u) return false;
+            const uint32_t rot = (dshard + 1u) & WF_SHARD;
+            const uint32_t m = (open >> rot) | (open << ((32u - rot) & 31u));    // the open ranges from `rot` on, cyclically
+            wflags = (wflags & ~WF_SHARD) | ((rot + (uint32_t)__builtin_ctz(m)) & WF_SHARD);
+        }
+    };
+    // RESIDENT: the path a lane carries from one trip of the loop to the next (else: this trip's ray)
+    bool valid = false;
+    f3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(1, 1, 1);
+    uint32_t pix = 0;
+    uint32_t lb = (uint32_t)bounce;                  // the bounce this lane's path is at (RESIDENT: per lane)
+    for (uint32_t R = blockIdx.x; RESIDENT || R * NW < total_chunks; R += RESIDENT ? 0u : gridDim.x, ++round) {     // (not RESIDENT: workgroup-uniform trip count)
         const unsigned long long tc0 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
 #if defined(PT_KO)
         // sensitivity experiments (profiles/r03/knockout.txt; never in the product build): extra work that changes no result,
@@ -1357,16 +1450,53 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
 #endif
         }
 #endif
-        uint32_t i;
-        bool valid = locate(cur, R, i);
-        const bool in_pool = valid;                               // the slot exists (COMPACT 0: it may hold a dead ray)
+        uint32_t i = 0;
+        bool in_pool = false;
+        if (RESIDENT) {
+            // refill: lanes without a path take the next rays of the wave's chunks, in pool order (consecutive addresses,
+            // whichever lanes are free), once `refill_min` lanes are free -- or none is busy
+            uint64_t vm = __ballot(valid);
+            uint32_t nfree = 64u - (uint32_t)__popcll(vm);
+            if ((wflags & WF_MORE) != 0u && (nfree >= (uint32_t)p.refill_min || vm == 0ull)) {
+                for (;;) {
+                    if (cpos == cend && !draw_chunk()) { wflags &= ~WF_MORE; break; }      // (also the first time: 0 == 0)
+                    const uint64_t fm = ~vm;
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                    const uint32_t avail = cend - cpos;
+                    if (!valid && rank < avail) {
+                        uint32_t k = cpos + rank;
+                        if (!dbgInRange(p, 1, k, (unsigned long long)p.segcap * (unsigned long long)p.nshard)) k = 0u;
+                        const v2f c_ = nt_load(reinterpret_cast<const v2f *>(&in.c[k]));
+                        const v4f a_ = nt_load(reinterpret_cast<const v4f *>(&in.a[k]));
+                        const v4f b_ = nt_load(reinterpret_cast<const v4f *>(&in.b[k]));
+                        pix = __float_as_uint(c_.y);
+                        o = mk(a_.x, a_.y, a_.z);
+                        d = mk(a_.w, b_.x, b_.y);
+                        T = mk(b_.z, b_.w, c_.x);
+                        lb = (uint32_t)bounce;
+                        valid = true;
+                    }
+                    const uint32_t took = nfree < avail ? nfree : avail;
+                    cpos += took;
+                    nfree -= took;
+                    if (nfree == 0u) break;
+                    vm = __ballot(valid);
+                }
+            }
+            if (__ballot(valid) == 0ull) break;                   // pool drained and every path of the wave has ended
+        } else {
+            valid = locate(cur, R, i);
+            in_pool = valid;                                      // the slot exists (COMPACT 0: it may hold a dead ray)
+            o = mk(0, 0, 0); d = mk(0, 0, 0); T = mk(1, 1, 1);
+            pix = 0;
+        }
         const uint32_t chunk_first_ray = (R * NW + wave) * 64u;   // (bounce 0: rays are numbered slot by slot, pixel by pixel)
-        f3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(1, 1, 1);
-        uint32_t pix = 0;
+        const bool lastb = RESIDENT ? (lb == (uint32_t)(p.depth - 1)) : last;      // (RESIDENT: per lane)
         MotionTime mt;
         mt.k = 0u;
         mt.f = 0.0f;
-        if (FIRST) {
+        if (RESIDENT) {
+        } else if (FIRST) {
             if (valid) {
                 // raycastFromCameraKernel: jittered pinhole ray through tile-local pixel pl of iteration slot
                 // With at least 64 pixels per slot, 64 consecutive ray indices meet at most one slot boundary: the slot
@@ -1515,10 +1645,10 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                         const f3 col = mk(s_mats[M_CR * p.nM + m], s_mats[M_CG * p.nM + m], s_mats[M_CB * p.nM + m]);
                         L = emit * (T * col);
                     }
-                } else if (!last || NEE) {
+                } else if (!lastb || NEE) {
                     // calculateBSDF: pick the lobe, build the next ray
                     const uint32_t slot = NEE ? ((pix >> SLOT_SHIFT) & (uint32_t)(MAXSLOT - 1)) : (pix >> SLOT_SHIFT);
-                    const uint32_t kb = s_key[slot];
+                    const uint32_t kb = RESIDENT ? s_keys[lb * (uint32_t)MAXSLOT + slot] : s_key[slot];
                     // the bounce's draws in stream order u_select, xi1, xi2, u_rr, then (light sampling) u_light, u_seed or
                     // (inside a medium) u_sd, u_s2, u_s3: each by its own jump from the seed, computed where it is used
                     const uint32_t s0 = minstd_seed(wang_hash(globalPixel(p, pix & PIX_MASK) ^ kb));
@@ -1609,7 +1739,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                             Ld = wgt * ((T * col) * (s_mats[M_EMIT * p.nM + lm] * lcol));
                         }
                     }
-                    if (!last) {
+                    if (!lastb) {
                     f3 nd;
                     f3 bias_n = nf;
                     float bias = 0.0002f;                 // RAY_BIAS_AMOUNT, ref: src/utilities.h:26
@@ -1696,7 +1826,7 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
                     if (!scattered) o = h.p + bias * bias_n;
                     d = nd;
                     alive = true;
-                    if (p.rr_start >= 0 && bounce >= p.rr_start) {      // Russian roulette
+                    if (p.rr_start >= 0 && (RESIDENT ? (int)lb : bounce) >= p.rr_start) {      // Russian roulette
                         float q = T.x;
                         if (T.y > q) q = T.y;
                         if (T.z > q) q = T.z;
@@ -1752,6 +1882,14 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
         const unsigned long long c3 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
         if (DEBUG_PHASE) { ph[0] += c1 - tc0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[4] += 1; }
         if (DEBUG_PHASE2 && !FIRST) { ph[0] += c1 - tc0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[4] += 1; ph5 += h.dbg0; ph6 += h.dbg1; }
+        if (RESIDENT) {
+            // a path that ended is counted at the bounce it ended at (the per-bounce live counts follow from the histogram);
+            // one that goes on stays where it is, a bounce further
+            if (valid && !alive) atomicAdd(&s_term[lb], 1u);
+            valid = alive;
+            lb += 1u;
+            continue;
+        }
         if (last) continue;      // wave-uniform: nothing survives the last bounce
 
         if (COMPACT != 0) {
@@ -1808,6 +1946,15 @@ __global__ __launch_bounds__(WG, (WG <= 256 && FEAT == 0) ? 5 : 1) void k_bounce
     if (COMPACT == 0) {
         if (lane == 0 && live_count) atomicAdd(&st->counts[cnt_index(bounce, 0)], live_count);
     }
+    if (RESIDENT) {
+        // live rays entering bounce b = the paths that ended at b or later (every path that enters the launch ends in it)
+        __syncthreads();
+        if (tid > bounce && tid < p.depth) {
+            uint32_t sum = 0;
+            for (int e = tid; e < p.depth; ++e) sum += s_term[e];
+            if (sum) atomicAdd(&st->counts[cnt_index(tid, (int)(blockIdx.x & (uint32_t)(NSHARD - 1)))], sum);
+        }
+    }
     if (NEE) {
         if (lane == 0 && shadow_count) atomicAdd(&st->shadow_rays, (unsigned long long)shadow_count);
     }
@@ -1858,6 +2005,12 @@ static const void *bounce_fn_feat(bool first)
 template <int WG, int GEOM>
 static const void *bounce_fn_geom(bool first, int compact, int feat)
 {
+    if ((feat & FEAT_RESIDENT) != 0) {        // resident paths: the pair queue and the batched walks, plain kernels, workgroups of 256 / 512
+        if constexpr ((GEOM == GEOM_PAIR || GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) && (WG == 256 || WG == 512)) {
+            if (feat == FEAT_RESIDENT && compact == 1 && !first) return (const void *)k_bounce<WG, false, GEOM, 1, FEAT_RESIDENT>;
+        }
+        return nullptr;
+    }
     if (feat != 0) {
         if (compact != 1) return nullptr;
         if ((feat & FEAT_MOTION) != 0) {      // per-ray shutter time: the scalar and the pair path, 256-thread workgroups only

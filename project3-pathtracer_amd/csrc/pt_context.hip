@@ -17,6 +17,14 @@
 #include "pt_internal.h"
 #include "pt_scene.h"
 
+// library choices of the resident-path launch (pt_options.resident == 0; measurements in DESIGN.md section 5.1)
+#ifndef PT_RESIDENT_DEFAULT
+#define PT_RESIDENT_DEFAULT (-1)
+#endif
+#ifndef PT_REFILL_MIN_DEFAULT
+#define PT_REFILL_MIN_DEFAULT 16
+#endif
+
 namespace {
 thread_local std::string g_last_error;
 }
@@ -879,6 +887,23 @@ int configure(pt_ctx *c)
         return fail(PT_ERR_INVALID, "scatter needs workgroup 0, 256 or 512 (got %d)", cfg.workgroup);
     k.cull = (k.nG > 32 && !getenv("PT_NO_CULL")) ? 1 : 0;
     k.nshard = (cfg.compact == 1) ? pt::NSHARD : 1;
+    // resident paths (pt_options.resident): the camera launch as ever, then ONE launch that traces bounces 1 .. depth - 1 with the
+    // paths kept in registers -- where a kernel instance exists (pair queue / batched walks, plain kernels) and there is more
+    // than one later bounce to fuse; everything else keeps the launch per bounce
+    {
+        int want = o.resident;
+        if (want == 0 && getenv("PT_RESIDENT")) want = atoi(getenv("PT_RESIDENT")) > 0 ? 1 : -1;      // (only when the option leaves the choice open)
+        if (want == 0) want = PT_RESIDENT_DEFAULT;
+        cfg.resident = 0;
+        if (want > 0 && k.depth >= 3) {
+            pt::LaunchCfg t = cfg;
+            if ((t.geom == 6 || t.geom == 7) && o.workgroup == 0) t.workgroup = 512;     // (the walks pick 256 or 512 below: both exist)
+            cfg.resident = pt::bounce_resident_available(t) ? 1 : 0;
+        }
+        k.refill_min = getenv("PT_REFILL_MIN") ? atoi(getenv("PT_REFILL_MIN")) : PT_REFILL_MIN_DEFAULT;
+        if (k.refill_min < 1) k.refill_min = 1;
+        if (k.refill_min > 64) k.refill_min = 64;
+    }
     size_t lds = pt::bounce_lds_bytes(k, cfg);
     if ((cfg.geom == 6 || cfg.geom == 7) && o.workgroup == 0) {
         // the batched walk keeps 4.5 KiB of LDS per wave beside the node copy: take the workgroup size that puts most
@@ -936,9 +961,10 @@ int configure(pt_ctx *c)
     if (grid > want) grid = want;
     if (grid < 1) grid = 1;
     cfg.grid = (int)grid;
+    if (cfg.resident && !pt::bounce_resident_available(cfg)) cfg.resident = 0;      // (a fallback above changed the launch shape)
     if (getenv("PT_DEBUG_CLOCK"))
-        fprintf(stderr, "[ptamd] launch: geom %d, workgroup %d, %zu B LDS, %d workgroups/CU, grid %d, batch %d\n", cfg.geom, cfg.workgroup,
-                lds, per_cu, cfg.grid, batch);
+        fprintf(stderr, "[ptamd] launch: geom %d, workgroup %d, %zu B LDS, %d workgroups/CU, grid %d, batch %d, resident paths %d (refill at %d free lanes)\n", cfg.geom, cfg.workgroup,
+                lds, per_cu, cfg.grid, batch, cfg.resident, k.refill_min);
 
     // Launch sequences in flight: sequence q renders batches q, q + nseq, ... of a pt_render call on a stream of its own,
     // with its own ray pools, radiance planes and IterState; only the accumulates are ordered across the sequences
@@ -947,7 +973,8 @@ int configure(pt_ctx *c)
     // Library choice: two (config 2 on one box: 37.2 / 43.0 / 42.9 / 41.4 G ray-bounces/s with 1 / 2 / 3 / 4 sequences;
     // config 5: 17.7 / 20.5 / 19.7 / 18.8 G -- profiles/r03/sweep_sequences.txt).
     int nseq = o.sequences == 0 ? 2 : o.sequences;
-    if (getenv("PT_SEQUENCES") && atoi(getenv("PT_SEQUENCES")) >= 1 && atoi(getenv("PT_SEQUENCES")) <= PT_MAX_SEQUENCES)
+    // (the environment only where the option leaves the choice to the library; pt_get_launch_info reports what was taken)
+    if (o.sequences == 0 && getenv("PT_SEQUENCES") && atoi(getenv("PT_SEQUENCES")) >= 1 && atoi(getenv("PT_SEQUENCES")) <= PT_MAX_SEQUENCES)
         nseq = atoi(getenv("PT_SEQUENCES"));
     c->nseq = nseq;
     // per-iteration radiance planes (one write per path, folded into the image by k_accumulate), per sequence
@@ -1175,11 +1202,14 @@ int configure(pt_ctx *c)
 // ev (optional): 2*depth events recorded around the bounce launches (pt_render_profiled).
 // sq: the launch sequence (its pools, planes and IterState); with_accumulate = false leaves the accumulate to the caller,
 // who orders it behind the previous batch's.
+int bounce_launches_per_batch(const pt_ctx *c) { return c->cfg.resident ? 2 : c->kp.depth; }
+
 int enqueue_batch(pt_ctx *c, hipStream_t s, hipEvent_t *ev, int sq = 0, bool with_accumulate = true)
 {
     const pt::KParams &kp = c->kps[sq];
     HIP_TRY(pt::launch_iter_begin(s, kp.st, kp.npix, kp.depth, c->cfg.compact));
-    for (int b = 0; b < kp.depth; ++b) {
+    const int launches = bounce_launches_per_batch(c);      // (resident paths: the camera launch + one for all later bounces)
+    for (int b = 0; b < launches; ++b) {
         if (ev) HIP_TRY(hipEventRecord(ev[2 * b], s));
         HIP_TRY(pt::launch_bounce(s, kp, c->cfg, b));
         if (ev) HIP_TRY(hipEventRecord(ev[2 * b + 1], s));
@@ -1279,7 +1309,7 @@ int render_batch_ordered(pt_ctx *c, hipStream_t ss, int iter_first, int count, h
     HIP_TRY(pt::launch_iter_fold(ss, c->d_state, c->kp.depth));
     if (done_ev) HIP_TRY(hipEventRecord(done_ev, ss));
     c->batches_stamped++;
-    c->bounce_launches += (unsigned long long)c->kp.depth;
+    c->bounce_launches += (unsigned long long)bounce_launches_per_batch(c);
     c->image_valid = true;
     return PT_OK;
 }
@@ -1289,7 +1319,9 @@ int render_batch_ordered(pt_ctx *c, hipStream_t ss, int iter_first, int count, h
 extern "C" {
 
 const char *pt_last_error(void) { return g_last_error.c_str(); }
-const char *pt_version(void) { return "ptamd 0.1 (gfx950, abi 1)"; }
+const char *pt_version(void) { return "ptamd 0.1 (gfx950, abi 2)"; }
+int pt_abi_version(void) { return PT_ABI_VERSION; }
+size_t pt_options_size(void) { return sizeof(pt_options); }
 
 int pt_strip_local_rows(int height, int strip_rows, int world, int rank)
 {
@@ -1431,6 +1463,7 @@ int pt_set_options(pt_ctx *c, const pt_options *o)
         return fail(PT_ERR_INVALID, "lens radius %g / focal distance %g", (double)o->lens_radius, (double)o->focal_distance);
     if (o->motion_per_ray < 0 || o->motion_per_ray > 1) return fail(PT_ERR_INVALID, "motion_per_ray %d not 0 or 1", o->motion_per_ray);
     if (o->sequences < 0 || o->sequences > PT_MAX_SEQUENCES) return fail(PT_ERR_INVALID, "sequences %d not in 0..%d", o->sequences, PT_MAX_SEQUENCES);
+    if (o->resident < -1 || o->resident > 1) return fail(PT_ERR_INVALID, "resident %d not -1, 0 or 1", o->resident);
     if (o->direct_light && o->compaction != 1) return fail(PT_ERR_INVALID, "direct_light needs compaction 1 (got %d)", o->compaction);
     if (o->scatter && o->compaction != 1) return fail(PT_ERR_INVALID, "scatter needs compaction 1 (got %d)", o->compaction);
     c->opt = *o;
@@ -1758,8 +1791,26 @@ int pt_render(pt_ctx *c, int iter_first, int iter_count)
         }
     }
     HIP_TRY(hipEventRecord(e1, s));
-    c->bounce_launches += (unsigned long long)nb * (unsigned long long)c->kp.depth;
+    c->bounce_launches += (unsigned long long)nb * (unsigned long long)bounce_launches_per_batch(c);
     c->image_valid = true;
+    return PT_OK;
+}
+
+int pt_get_launch_info(pt_ctx *c, pt_launch_info *out)
+{
+    if (!c || !out) return fail(PT_ERR_INVALID, "pt_get_launch_info: NULL argument");
+    int rc = configure(c);
+    if (rc != PT_OK) return rc;
+    memset(out, 0, sizeof *out);
+    out->geom_path = c->cfg.geom + 1;
+    out->workgroup = c->cfg.workgroup;
+    out->grid = c->cfg.grid;
+    out->batch = c->batch;
+    out->sequences = c->nseq;
+    out->resident = c->cfg.resident;
+    out->refill_min = c->kp.refill_min;
+    out->launches_per_batch = bounce_launches_per_batch(c);
+    out->lds_bytes = (int)pt::bounce_lds_bytes(c->kp, c->cfg);
     return PT_OK;
 }
 
@@ -1788,7 +1839,7 @@ int pt_render_profiled(pt_ctx *c, int iter_first, int iter_count, double *bounce
         launches++;
         c->batches_stamped++;
         HIP_TRY(hipStreamSynchronize(s));
-        for (int b = 0; b < depth; ++b) {
+        for (int b = 0; b < bounce_launches_per_batch(c); ++b) {      // (resident paths: [1] = the one launch of all later bounces)
             float ms = 0.0f;
             HIP_TRY(hipEventElapsedTime(&ms, ev[2 * b], ev[2 * b + 1]));
             bounce_ms_out[b] += (double)ms;
@@ -1797,7 +1848,7 @@ int pt_render_profiled(pt_ctx *c, int iter_first, int iter_count, double *bounce
     HIP_TRY(pt::launch_iter_fold(s, c->d_state, depth));
     HIP_TRY(hipStreamSynchronize(s));
     for (auto &e : ev) (void)hipEventDestroy(e);
-    c->bounce_launches += (unsigned long long)launches * (unsigned long long)depth;
+    c->bounce_launches += (unsigned long long)launches * (unsigned long long)bounce_launches_per_batch(c);
     c->image_valid = true;
     return PT_OK;
 }

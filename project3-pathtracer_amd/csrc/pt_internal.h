@@ -45,6 +45,10 @@ struct IterState {
     uint32_t serial;
     uint32_t pad[24];
     uint32_t counts[(PT_MAX_DEPTH + 1) * NSHARD * CNT_STRIDE];   // live rays entering bounce b, per segment
+    // resident paths: the waves of the one later-bounce launch DRAW their 64-ray chunks of the pool instead of being dealt equal
+    // shares (the SIMDs favour their oldest waves: with equal shares the first workgroup of a CU leaves at 55 % of the launch and
+    // the CU runs out its last third with ever fewer waves) -- NSHARD counters, each over its own range of chunks, own 128-B lines
+    uint32_t draw[NSHARD * CNT_STRIDE];
     unsigned long long live_in[PT_MAX_DEPTH];    // summed over segments and iterations (stats)
     unsigned long long iterations;
     unsigned long long clk[4];                   // diagnostics: shader-clock / real-time ticks spent by workgroup 0 of the last bounce-1 launch
@@ -116,6 +120,7 @@ struct KParams {
     const float *knot_cam; // [nknots][12]: camera position, view, up (xyz each, padded to 4)
     int nknots;            // 0 = off
     float tan_x, tan_y;    // tan of the half field-of-view angles (the per-ray camera basis is built on the device)
+    int refill_min;        // resident paths (FEAT_RESIDENT kernels): a wave refills its free lanes from the pool once this many are free
 };
 
 struct LaunchCfg {
@@ -127,6 +132,8 @@ struct LaunchCfg {
     int nee;         // 1 = explicit light sampling at diffuse vertices (compact must be 1)
     int media;       // 1 = subsurface random walk inside SCATTER materials (compact must be 1, workgroup 256 or 512)
     int motion;      // 1 = per-ray shutter time (geom 0, workgroup 256, compact 1, neither nee nor media)
+    int resident;    // 1 = bounces 1 .. depth - 1 in ONE launch, paths resident in registers (geom 4, 6, 7; workgroup 256 / 512; compact 1;
+                     //     none of nee / media / motion)
 };
 
 // kernels (pt_kernels.hip)
@@ -141,7 +148,8 @@ hipError_t launch_device_kat(hipStream_t s, int op, const float *in, float *out,
 // error reporting shared by the C-ABI translation units: records the message behind pt_last_error(), returns `code`
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
-size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg);
+size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg);      // (cfg.resident: of the resident-path kernel)
 int bounce_max_blocks_per_cu(const KParams &p, const LaunchCfg &cfg);
+bool bounce_resident_available(const LaunchCfg &cfg);                  // is there a resident-path kernel for this launch shape?
 
 }  // namespace pt

@@ -175,6 +175,7 @@ __global__ void k_iter_begin(IterState *st, uint32_t npix, int depth, int compac
         }
         if (b < depth) st->live_in[b] += sum;
     }
+    if (b < NSHARD) st->draw[b * CNT_STRIDE] = 0u;    // (resident paths: chunk draw counters of the later-bounce launch)
     if (b == 0) {
         st->serial += (uint32_t)PT_MAX_SEQUENCES;     // (stays congruent to the sequence's number: pt_create)
         st->iter = iter;
@@ -267,7 +268,9 @@ size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg)
     size_t mats = (size_t)((p.nM * M_PLANES + 3) & ~3) * sizeof(float);
     size_t scan = (size_t)((2 * (cfg.workgroup / 64) + 2 + 3) & ~3) * sizeof(uint32_t);
     static const size_t extra = getenv("PT_EXTRA_LDS") ? (size_t)atol(getenv("PT_EXTRA_LDS")) : 0;   // occupancy experiments
-    return prim + queue + mats + scan + extra;
+    // resident paths: stream keys of every (bounce, slot) and the histogram of the bounces the paths ended at
+    const size_t resident = cfg.resident ? (size_t)(p.depth * MAXSLOT + ((p.depth + 3) & ~3)) * sizeof(uint32_t) : 0;
+    return prim + queue + mats + scan + resident + extra;
 }
 
 // one translation unit per geometry path (pt_bounce_g<N>.hip)
@@ -282,17 +285,25 @@ const void *bounce_kernel_g7(int workgroup, bool first, int compact, int feat);
 
 static const void *select_bounce(const LaunchCfg &cfg, bool first)
 {
+    const int feat = cfg.nee | (cfg.media << 1) | (cfg.motion << 2) | ((cfg.resident && !first) ? FEAT_RESIDENT : 0);
     switch (cfg.geom) {
-    case GEOM_SCALAR: return bounce_kernel_g0(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1) | (cfg.motion << 2));
-    case GEOM_LDS: return bounce_kernel_g1(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1) | (cfg.motion << 2));
-    case GEOM_QUEUE: return bounce_kernel_g2(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1) | (cfg.motion << 2));
-    case GEOM_BVH: return bounce_kernel_g3(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1) | (cfg.motion << 2));
-    case GEOM_PAIR: return bounce_kernel_g4(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1) | (cfg.motion << 2));
-    case GEOM_WALK_PAIR: return bounce_kernel_g5(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1) | (cfg.motion << 2));
-    case GEOM_WALK4: return bounce_kernel_g6(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1) | (cfg.motion << 2));
-    case GEOM_WALK4G: return bounce_kernel_g7(cfg.workgroup, first, cfg.compact, cfg.nee | (cfg.media << 1) | (cfg.motion << 2));
+    case GEOM_SCALAR: return bounce_kernel_g0(cfg.workgroup, first, cfg.compact, feat);
+    case GEOM_LDS: return bounce_kernel_g1(cfg.workgroup, first, cfg.compact, feat);
+    case GEOM_QUEUE: return bounce_kernel_g2(cfg.workgroup, first, cfg.compact, feat);
+    case GEOM_BVH: return bounce_kernel_g3(cfg.workgroup, first, cfg.compact, feat);
+    case GEOM_PAIR: return bounce_kernel_g4(cfg.workgroup, first, cfg.compact, feat);
+    case GEOM_WALK_PAIR: return bounce_kernel_g5(cfg.workgroup, first, cfg.compact, feat);
+    case GEOM_WALK4: return bounce_kernel_g6(cfg.workgroup, first, cfg.compact, feat);
+    case GEOM_WALK4G: return bounce_kernel_g7(cfg.workgroup, first, cfg.compact, feat);
     default: return nullptr;
     }
+}
+
+bool bounce_resident_available(const LaunchCfg &cfg)
+{
+    LaunchCfg t = cfg;
+    t.resident = 1;
+    return !cfg.nee && !cfg.media && !cfg.motion && cfg.compact == 1 && select_bounce(t, false) != nullptr;
 }
 
 int bounce_max_blocks_per_cu(const KParams &p, const LaunchCfg &cfg)
@@ -313,15 +324,18 @@ int bounce_max_blocks_per_cu(const KParams &p, const LaunchCfg &cfg)
     return nb;
 }
 
+// cfg.resident: bounce 0 is the camera kernel as ever, bounce 1 the ONE launch that traces bounces 1 .. depth - 1
 hipError_t launch_bounce(hipStream_t s, const KParams &p, const LaunchCfg &cfg, int bounce)
 {
-    const void *fn = select_bounce(cfg, bounce == 0);
+    LaunchCfg lc = cfg;
+    if (bounce == 0) lc.resident = 0;
+    const void *fn = select_bounce(lc, bounce == 0);
     if (!fn) return hipErrorInvalidValue;
     KParams pc = p;
     int b = bounce;
     void *args[] = {(void *)&pc, (void *)&b};
     return hipLaunchKernel(fn, dim3((unsigned)cfg.grid), dim3((unsigned)cfg.workgroup), args,
-                           bounce_lds_bytes(p, cfg), s);
+                           bounce_lds_bytes(p, lc), s);
 }
 
 hipError_t launch_iter_set(hipStream_t s, IterState *st, uint32_t iter_first, uint32_t q, uint32_t r, uint32_t j0, uint32_t stride)

@@ -44,6 +44,11 @@ def main():
         iters = int(rng.integers(1, 5))
         opts = dict(rr_start=int(rng.integers(-1, depth)), seed=int(rng.integers(0, 1000)))
         gopts = dict(geom_path=int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8] if case % 3 == 0 else [0, 1, 2, 3, 4, 5, 6, 7])), batch=int(rng.choice([0, 1, 2, 3, 7, 16])))
+        # round 4: resident paths (one launch for all later bounces) on or off, and the number of free lanes that triggers a
+        # wave's refill -- from a generator of its own, so that the cases of the earlier rounds stay what they were
+        rng4 = np.random.default_rng(770000 + case)
+        gopts["resident"] = int(rng4.choice([-1, 1, 1]))
+        os.environ["PT_REFILL_MIN"] = str(int(rng4.choice([1, 4, 16, 33, 64])))
         if rng.random() < 0.4:
             opts["direct_light"] = 1
         if rng.random() < 0.4:

@@ -86,7 +86,9 @@ def test_pod_layouts_match_reference(pkg, golden):
             assert getattr(cls, name).offset == lay[key][name], (key, name)
     assert C.sizeof(pkg.Mat4) == lay["cudaMat4"]
     # the binding's Options/Stats mirror the header
-    assert C.sizeof(pkg.Options) == 20 * 4
+    assert C.sizeof(pkg.Options) == 21 * 4 == pkg.lib().pt_options_size()
+    assert pkg.lib().pt_abi_version() == pkg.PT_ABI_VERSION == 2
+    assert C.sizeof(pkg.LaunchInfo) == 16 * 4
     assert C.sizeof(pkg.Stats) == 8 * 2 + 8 * pkg.PT_MAX_DEPTH + 8 + 8 + 8
 
 

@@ -1272,3 +1272,71 @@ def test_fuzz_sample(pkg):
         assert fuzz_gpu.main() == 0
     finally:
         sys.argv = old
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# resident paths (pt_options.resident, round 4): the later bounces of a batch in ONE launch, paths kept in registers
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("scene,w,h,depth,iters,opts", [
+    ("sampleScene_spec.txt", 121, 67, 8, 19, {"batch": 16}),                     # pair queue, ragged tile, two batches
+    ("sampleScene_spec.txt", 64, 48, 3, 5, {"batch": 2}),                        # the shortest path that has anything to fuse
+    ("sampleScene_spec.txt", 200, 120, 8, 6, {"rr_start": 2, "batch": 3}),       # Russian roulette keyed on each lane's own bounce
+    ("cornell_glass.txt", 160, 90, 16, 4, {"batch": 4}),                         # refraction, 16 bounces
+    ("cloud256.txt", 160, 90, 12, 3, {"rotat": 1}),                              # batched 4-wide walk
+    ("cloud256.txt", 96, 54, 32, 2, {"rotat": 1, "rr_start": 3, "geom_path": 8}),  # ... nodes through L1/L2, depth 32
+    ("sampleScene_spec.txt", 7, 5, 6, 40, {"batch": 16}),                        # a tile smaller than a wave
+    ("sampleScene_spec.txt", 128, 72, 5, 9, {"workgroup": 512, "sequences": 1}),
+])
+def test_resident_paths_are_invisible(pkg, scene, w, h, depth, iters, opts):
+    """pt_options.resident = 1: the camera launch, then ONE launch in which a wave keeps the paths that go on in its registers
+    (per-lane bounce numbers, stream keys of every bounce from an LDS table) and refills the lanes of those that ended.  Image,
+    per-bounce live counts and launch counts: the oracle's, and the launch-per-bounce path's, bit for bit."""
+    o = dict(opts)
+    rotat = o.pop("rotat", 0)
+    a, la, sa = gpu_render(pkg, scene, w, h, depth, iters=iters, rotat=rotat, resident=-1, **o)
+    b, lb, sb = gpu_render(pkg, scene, w, h, depth, iters=iters, rotat=rotat, resident=1, **o)
+    c, lc = cpu_render(scene, w, h, depth, iters=iters, rotat=rotat, rr_start=o.get("rr_start", -1))
+    check(b, c, lb, lc, f"resident paths, {scene} {w}x{h} depth {depth}")
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and la == lb
+    nb = -(-iters // (o.get("batch", 0) or 16))
+    assert sa.bounce_launches == nb * depth and sb.bounce_launches == nb * 2, (sa.bounce_launches, sb.bounce_launches)
+
+
+@pytest.mark.parametrize("refill", [1, 7, 32, 64])
+def test_resident_paths_refill_thresholds(pkg, refill, monkeypatch):
+    """The number of free lanes that triggers a refill (PT_REFILL_MIN, read when a context configures) changes which lane and
+    which trip of a wave's loop traces a path -- and nothing else."""
+    monkeypatch.setenv("PT_REFILL_MIN", str(refill))
+    b, lb, _ = gpu_render(pkg, "sampleScene_spec.txt", 150, 83, 8, iters=5, batch=5, rr_start=3, resident=1)
+    c, lc = cpu_render("sampleScene_spec.txt", 150, 83, 8, iters=5, rr_start=3)
+    check(b, c, lb, lc, f"resident paths, refill at {refill} free lanes")
+
+
+def test_resident_paths_fall_back_where_no_kernel_exists(pkg):
+    """Direct lighting, scattering, the per-bounce geometry paths and depth < 3 keep one launch per bounce whatever the option
+    asks for: same image, launch count = depth."""
+    for opts, depth in (({"direct_light": 1}, 5), ({"geom_path": 1}, 5), ({"geom_path": 3}, 4), ({}, 2), ({}, 1)):
+        b, lb, sb = gpu_render(pkg, "sampleScene_spec.txt", 96, 54, depth, iters=3, batch=3, resident=1, **opts)
+        c, lc = cpu_render("sampleScene_spec.txt", 96, 54, depth, iters=3, **({"direct_light": 1} if "direct_light" in opts else {}))
+        check(b, c, lb, lc, f"resident asked for with {opts}, depth {depth}")
+        assert sb.bounce_launches == depth
+
+
+def test_resident_paths_on_strip_tiles_and_resume(pkg):
+    """Resident paths on an interleaved-strip tile (global pixel numbering), two sequences, several pt_render calls."""
+    from project3_pathtracer_amd import sharding
+    W, H, depth = 128, 72, 6
+    c, _ = cpu_render("sampleScene_spec.txt", W, H, depth, iters=21, rr_start=1)
+    sc = pkg.SceneFile(os.path.join(SCENES, "sampleScene_spec.txt"))
+    sc.set_resolution(W, H)
+    with pkg.Renderer(0) as r:
+        r.set_options(depth=depth, rr_start=1, batch=4, sequences=2, resident=1, strip_rows=8, strip_world=3, strip_rank=2)
+        r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
+        r.set_camera(sc.camera)
+        r.clear_image()
+        r.render(1, 9)
+        r.render(10, 1)
+        r.render(11, 11)
+        g = r.download_image()
+    want = c[sharding.strip_global_rows(H, 3, 2, 8)]
+    assert np.array_equal(g.view(np.uint32), want.view(np.uint32))
