@@ -97,6 +97,7 @@ struct Hit {
     float t;            // world-space distance to the hit
     bool any;
     unsigned long long dbg0, dbg1;   // DEBUG_PHASE2 builds: shader clocks of the pre-test loop / the last batches (else unused)
+    unsigned long long dbg2, dbg3;   //   ... of the full batches inside the loop; lane-clocks of the last batches (clocks x busy lanes)
 };
 
 // GEOM selects how the primitive list reaches the lanes:
@@ -627,6 +628,7 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
                                                f3 o, f3 d, bool valid, uint32_t lane, uint32_t primmask, MotionTime mymt = MotionTime())
 {
     const unsigned long long ph_in = (DEBUG_PHASE2 && !FIRST) ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long fb_clk = 0ull, lb_lane_clk = 0ull;      // DEBUG_PHASE2: clocks inside full batches; lane-clocks of the last batches
     q.key[lane] = KEY_NONE;
     q.org[lane] = make_float4(o.x, o.y, o.z, d.x);
     q.dir[lane] = make_float2(d.y, d.z);
@@ -664,11 +666,19 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
         if (type == 0u) {                                    // wave-uniform
             if (pass) q.q[0][(tail[0] + rank) & (QCAP - 1u)] = lane | ((uint32_t)g << 8);
             tail[0] += (uint32_t)__popcll(mask);
-            if (tail[0] - head[0] >= 64u) { pairBatch<0u, FIRST, PR, MOTION>(p, s_prims, q, head[0], 64u, lane); head[0] += 64u; }
+            if (tail[0] - head[0] >= 64u) {
+                const unsigned long long tb = (DEBUG_PHASE2 && !FIRST) ? __builtin_amdgcn_s_memtime() : 0ull;
+                pairBatch<0u, FIRST, PR, MOTION>(p, s_prims, q, head[0], 64u, lane); head[0] += 64u;
+                if (DEBUG_PHASE2 && !FIRST) fb_clk += __builtin_amdgcn_s_memtime() - tb;
+            }
         } else {
             if (pass) q.q[1][(tail[1] + rank) & (QCAP - 1u)] = lane | ((uint32_t)g << 8);
             tail[1] += (uint32_t)__popcll(mask);
-            if (tail[1] - head[1] >= 64u) { pairBatch<1u, FIRST, PR, MOTION>(p, s_prims, q, head[1], 64u, lane); head[1] += 64u; }
+            if (tail[1] - head[1] >= 64u) {
+                const unsigned long long tb = (DEBUG_PHASE2 && !FIRST) ? __builtin_amdgcn_s_memtime() : 0ull;
+                pairBatch<1u, FIRST, PR, MOTION>(p, s_prims, q, head[1], 64u, lane); head[1] += 64u;
+                if (DEBUG_PHASE2 && !FIRST) fb_clk += __builtin_amdgcn_s_memtime() - tb;
+            }
         }
     }
     const uint64_t dbg_valid = DEBUG_PAIR ? __ballot(valid) : 0ull;
@@ -683,15 +693,21 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
     const uint32_t left0 = tail[0] - head[0], left1 = tail[1] - head[1];      // both < 64
     if (left0 != 0u && left1 != 0u && left0 + left1 <= 64u) {
         pairBatch<2u, FIRST, PR, MOTION>(p, s_prims, q, head[0], left0, lane, head[1], left1);   // one mixed batch instead of two partial ones
+        if (DEBUG_PHASE2 && !FIRST) lb_lane_clk += (__builtin_amdgcn_s_memtime() - ph_a) * (unsigned long long)(left0 + left1);
     } else {
         if (left0 != 0u) pairBatch<0u, FIRST, PR, MOTION>(p, s_prims, q, head[0], left0, lane);
+        const unsigned long long ph_b = (DEBUG_PHASE2 && !FIRST) ? __builtin_amdgcn_s_memtime() : 0ull;
+        if (DEBUG_PHASE2 && !FIRST) lb_lane_clk += (ph_b - ph_a) * (unsigned long long)left0;
         if (left1 != 0u) pairBatch<1u, FIRST, PR, MOTION>(p, s_prims, q, head[1], left1, lane);
+        if (DEBUG_PHASE2 && !FIRST) lb_lane_clk += (__builtin_amdgcn_s_memtime() - ph_b) * (unsigned long long)left1;
     }
     wave_lds_fence();
     Hit h;
     if (DEBUG_PHASE2 && !FIRST) {
-        h.dbg0 = ph_a - ph_in;
+        h.dbg0 = ph_a - ph_in - fb_clk;                        // the pre-test loop without the full batches it ran
         h.dbg1 = __builtin_amdgcn_s_memtime() - ph_a;
+        h.dbg2 = fb_clk;
+        h.dbg3 = lb_lane_clk;
     }
     h.any = false;
     h.material = 0;
@@ -1318,9 +1334,12 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
     uint32_t shadow_count = 0;    // NEE: shadow rays this wave traced
     int round = 0;
     unsigned long long ph[5] = {0, 0, 0, 0, 0}, ph5 = 0, ph6 = 0;
+    // DEBUG_PHASE2: the lane budget of the later bounces -- per phase of a trip the shader clocks it took and the same weighted by
+    // the lanes that had work in it (IterState::lane_budget, printed by pt_get_stats under PT_DEBUG_PHASE2=1)
+    unsigned long long lbud[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t lb_nvalid = 0, lb_nhit = 0, lb_nbsdf = 0;
     // pool slot of this lane in the chunk workgroup-round R2 gives this wave, and whether there is a ray in it
-    auto locate = [&](Cursor &cu, uint32_t R2, uint32_t &slot_i) -> bool {
-        const uint32_t chunk = R2 * NW + wave;
+    auto locate = [&](Cursor &cu, uint32_t chunk, uint32_t &slot_i) -> bool {
         while (cu.sh + 1u < (uint32_t)NSHARD && chunk >= cu.c0 + ((cu.nseg + 63u) >> 6)) {
             cu.c0 += (cu.nseg + 63u) >> 6;
             cu.sh += 1u;
@@ -1340,6 +1359,10 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
     // returning atomic, read a trip or more later).  What a wave keeps between trips is three scalars: the next pool slot to
     // hand out, the end of the chunk in hand, and a word of flags (its counter, "a draw is in flight", "the pool has more");
     // chunk -> (segment, offset) goes through two 32-entry LDS tables (the batched walk has no scalar registers to spare).
+    // (The camera launch keeps its dealt chunks: with drawn ones its workgroups leave together too, and the OTHER launch sequence's
+    // launch, whose workgroups take the slots the leaving ones free, can no longer start inside it -- 51.2 -> 45.3 G ray-bounces/s
+    // on config 2 with two sequences, + 1.5 % with one: profiles/r04/ab_camera_drawn_chunks.txt.)
+    uint32_t *const draw_ctr = st->draw;
     __shared__ uint32_t s_cfirst[NSHARD];            // first chunk of each segment (chunks are numbered segment by segment)
     __shared__ uint32_t s_draw[2];                   // chunks in the pool, chunks per draw counter
     if (RESIDENT) {
@@ -1359,8 +1382,8 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
     // draw in flight across the nearest-hit search: it draws when it needs a chunk, every third trip or so, and the other waves
     // cover that round trip)
     constexpr bool DRAW_AHEAD = true;
-    // the next chunk of the pool for this wave: sets cpos / cend; false = the pool is used up
-    auto draw_chunk = [&]() -> bool {
+    // the next chunk of the pool for this wave (RESIDENT: sets cpos / cend); false = the pool is used up
+    auto draw_chunk = [&](uint32_t &chunk_out) -> bool {
         const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_draw[0]);
         const uint32_t Q = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_draw[1]);
         // chunks of counter `lane`'s range (lanes 0 .. NSHARD - 1)
@@ -1368,16 +1391,18 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
         const uint32_t size_l = (lane < NSHARD && hi_l > lo_l) ? hi_l - lo_l : 0u;
         for (;;) {
             const uint32_t dshard = wflags & WF_SHARD;
-            if ((wflags & WF_DRAWN) == 0u && lane == 0) drawn = atomicAdd(&st->draw[dshard * (uint32_t)CNT_STRIDE], 1u);
+            if ((wflags & WF_DRAWN) == 0u && lane == 0) drawn = atomicAdd(&draw_ctr[dshard * (uint32_t)CNT_STRIDE], 1u);
             const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)drawn);
             wflags &= ~WF_DRAWN;
             const uint32_t size = (uint32_t)__builtin_amdgcn_readlane((int)size_l, (int)dshard);
             if (idx < size) {
                 const uint32_t chunk = dshard * Q + idx;
                 if (DRAW_AHEAD) {
-                    if (lane == 0) drawn = atomicAdd(&st->draw[dshard * (uint32_t)CNT_STRIDE], 1u);  // the next one, used a trip or more later
+                    if (lane == 0) drawn = atomicAdd(&draw_ctr[dshard * (uint32_t)CNT_STRIDE], 1u);  // the next one, used a trip or more later
                     wflags |= WF_DRAWN;
                 }
+                chunk_out = chunk;
+                if (!RESIDENT) return true;
                 // chunk -> segment: the last segment that starts at or before it (an empty segment starts where the next one does)
                 const uint32_t cf = lane < NSHARD ? s_cfirst[lane] : 0xFFFFFFFFu;
                 const uint32_t sh = (uint32_t)__popcll(__ballot(cf <= chunk)) - 1u;
@@ -1389,7 +1414,7 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
             }
             // this range is used up: which ones are not?  (The counters only grow: a stale value can show a used-up range as
             // open -- the draw then says so --, never an open one as used up.)
-            const uint32_t seen = lane < NSHARD ? __hip_atomic_load(&st->draw[(uint32_t)lane * (uint32_t)CNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+            const uint32_t seen = lane < NSHARD ? __hip_atomic_load(&draw_ctr[(uint32_t)lane * (uint32_t)CNT_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
             const uint32_t open = (uint32_t)__ballot(seen < size_l);
             if (open == 0u) return false;
             const uint32_t rot = (dshard + 1u) & WF_SHARD;
@@ -1402,7 +1427,8 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
     f3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(1, 1, 1);
     uint32_t pix = 0;
     uint32_t lb = (uint32_t)bounce;                  // the bounce this lane's path is at (RESIDENT: per lane)
-    for (uint32_t R = blockIdx.x; RESIDENT || R * NW < total_chunks; R += RESIDENT ? 0u : gridDim.x, ++round) {     // (not RESIDENT: workgroup-uniform trip count)
+    for (uint32_t R = blockIdx.x; RESIDENT || R * NW < total_chunks; R += RESIDENT ? 0u : gridDim.x, ++round) {     // (dealt chunks: workgroup-uniform trip count)
+        const uint32_t my_chunk = R * NW + wave;                  // dealt: round-robin over the workgroups' waves
         const unsigned long long tc0 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
 #if defined(PT_KO)
         // sensitivity experiments (profiles/r03/knockout.txt; never in the product build): extra work that changes no result,
@@ -1432,7 +1458,7 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
                 Cursor kc = cur;
                 uint32_t ki;
                 float acc = 0.0f;
-                if (locate(kc, R, ki)) {
+                if (locate(kc, my_chunk, ki)) {
 #pragma unroll
                     for (int k = 0; k < PT_KO_N; ++k) {
                         const float4 a4 = out.a[ki + 64u * (uint32_t)k];
@@ -1459,7 +1485,8 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
             uint32_t nfree = 64u - (uint32_t)__popcll(vm);
             if ((wflags & WF_MORE) != 0u && (nfree >= (uint32_t)p.refill_min || vm == 0ull)) {
                 for (;;) {
-                    if (cpos == cend && !draw_chunk()) { wflags &= ~WF_MORE; break; }      // (also the first time: 0 == 0)
+                    uint32_t dchunk;
+                    if (cpos == cend && !draw_chunk(dchunk)) { wflags &= ~WF_MORE; break; }      // (also the first time: 0 == 0)
                     const uint64_t fm = ~vm;
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
                     const uint32_t avail = cend - cpos;
@@ -1485,12 +1512,12 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
             }
             if (__ballot(valid) == 0ull) break;                   // pool drained and every path of the wave has ended
         } else {
-            valid = locate(cur, R, i);
+            valid = locate(cur, my_chunk, i);
             in_pool = valid;                                      // the slot exists (COMPACT 0: it may hold a dead ray)
             o = mk(0, 0, 0); d = mk(0, 0, 0); T = mk(1, 1, 1);
             pix = 0;
         }
-        const uint32_t chunk_first_ray = (R * NW + wave) * 64u;   // (bounce 0: rays are numbered slot by slot, pixel by pixel)
+        const uint32_t chunk_first_ray = my_chunk * 64u;          // (bounce 0: rays are numbered slot by slot, pixel by pixel)
         const bool lastb = RESIDENT ? (lb == (uint32_t)(p.depth - 1)) : last;      // (RESIDENT: per lane)
         MotionTime mt;
         mt.k = 0u;
@@ -1624,6 +1651,8 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
                                                 : nearestHit<GEOM, FIRST>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane, primmask);
         }
         const unsigned long long c2 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
+        if (DEBUG_PHASE2 && !FIRST) { lb_nvalid = (uint32_t)__popcll(__ballot(valid)); lb_nhit = (uint32_t)__popcll(__ballot(valid && h.any)); }
+        bool did_bsdf = false;            // (DEBUG_PHASE2)
         f3 L = mk(0, 0, 0);               // radiance this vertex adds to the path's sample
         // direct lighting: the shadow ray this lane wants traced and what it is worth if the light is visible
         bool want_shadow = false;
@@ -1647,6 +1676,7 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
                     }
                 } else if (!lastb || NEE) {
                     // calculateBSDF: pick the lobe, build the next ray
+                    did_bsdf = true;
                     const uint32_t slot = NEE ? ((pix >> SLOT_SHIFT) & (uint32_t)(MAXSLOT - 1)) : (pix >> SLOT_SHIFT);
                     const uint32_t kb = RESIDENT ? s_keys[lb * (uint32_t)MAXSLOT + slot] : s_key[slot];
                     // the bounce's draws in stream order u_select, xi1, xi2, u_rr, then (light sampling) u_light, u_seed or
@@ -1881,13 +1911,25 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
 
         const unsigned long long c3 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
         if (DEBUG_PHASE) { ph[0] += c1 - tc0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[4] += 1; }
-        if (DEBUG_PHASE2 && !FIRST) { ph[0] += c1 - tc0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[4] += 1; ph5 += h.dbg0; ph6 += h.dbg1; }
+        if (DEBUG_PHASE2 && !FIRST) { ph[0] += c1 - tc0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[4] += 1; ph5 += h.dbg0 + h.dbg2; ph6 += h.dbg1; }
+        if (DEBUG_PHASE2 && !FIRST && GEOM == GEOM_PAIR) {
+            lb_nbsdf = (uint32_t)__popcll(__ballot(did_bsdf));
+            const unsigned long long res = (c2 - c1) - h.dbg0 - h.dbg1 - h.dbg2;
+            lbud[0] += c1 - tc0;  lbud[1] += (c1 - tc0) * lb_nvalid;          // load / refill
+            lbud[2] += h.dbg0;    lbud[3] += h.dbg0 * lb_nvalid;              // pre-test loop
+            lbud[4] += h.dbg2;                                                 // full batches: 64 lanes
+            lbud[5] += h.dbg1;    lbud[6] += h.dbg3;                           // last batches
+            lbud[7] += res;       lbud[8] += res * lb_nhit;                    // result (winner's normal, material)
+            lbud[9] += c3 - c2;   lbud[10] += (c3 - c2) * lb_nbsdf;            // shading + radiance write
+            lbud[13] += 1;        lbud[14] += lb_nvalid;
+        }
         if (RESIDENT) {
             // a path that ended is counted at the bounce it ended at (the per-bounce live counts follow from the histogram);
             // one that goes on stays where it is, a bounce further
             if (valid && !alive) atomicAdd(&s_term[lb], 1u);
             valid = alive;
             lb += 1u;
+            if (DEBUG_PHASE2 && GEOM == GEOM_PAIR) { const unsigned long long c4 = __builtin_amdgcn_s_memtime() - c3; lbud[11] += c4; lbud[12] += c4 * (unsigned long long)__popcll(__ballot(alive)); }
             continue;
         }
         if (last) continue;      // wave-uniform: nothing survives the last bounce
@@ -1941,7 +1983,11 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
                 }
             }
         }
-        if (DEBUG_PHASE2 && !FIRST) ph[3] += __builtin_amdgcn_s_memtime() - c3;
+        if (DEBUG_PHASE2 && !FIRST) {
+            const unsigned long long c4 = __builtin_amdgcn_s_memtime() - c3;
+            ph[3] += c4;
+            if (GEOM == GEOM_PAIR) { lbud[11] += c4; lbud[12] += c4 * (unsigned long long)__popcll(__ballot(alive)); }      // compaction + pool write
+        }
     }
     if (COMPACT == 0) {
         if (lane == 0 && live_count) atomicAdd(&st->counts[cnt_index(bounce, 0)], live_count);
@@ -1957,6 +2003,10 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
     }
     if (NEE) {
         if (lane == 0 && shadow_count) atomicAdd(&st->shadow_rays, (unsigned long long)shadow_count);
+    }
+    if (DEBUG_PHASE2 && !FIRST && GEOM == GEOM_PAIR && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) atomicAdd(&st->lane_budget[k], lbud[k]);
     }
     if (DEBUG_PHASE2 && !FIRST && lane == 0) {
         atomicAdd(&st->dbg[1], ph5);

@@ -19,10 +19,10 @@
 
 // library choices of the resident-path launch (pt_options.resident == 0; measurements in DESIGN.md section 5.1)
 #ifndef PT_RESIDENT_DEFAULT
-#define PT_RESIDENT_DEFAULT (-1)
+#define PT_RESIDENT_DEFAULT 1
 #endif
 #ifndef PT_REFILL_MIN_DEFAULT
-#define PT_REFILL_MIN_DEFAULT 16
+#define PT_REFILL_MIN_DEFAULT 8
 #endif
 
 namespace {
@@ -1979,6 +1979,23 @@ int pt_get_stats(pt_ctx *c, pt_stats *out)
                         "result %.0f) | shade + radiance write %.0f | compaction + pool write %.0f\n",
                 (double)h.dbg[0] / h.dbg[7], (double)h.dbg[3] / h.dbg[7], (double)h.dbg[1] / h.dbg[7], (double)h.dbg[2] / h.dbg[7],
                 ((double)h.dbg[3] - (double)h.dbg[1] - (double)h.dbg[2]) / h.dbg[7], (double)h.dbg[4] / h.dbg[7], (double)h.dbg[5] / h.dbg[7]);
+    if (getenv("PT_DEBUG_PHASE2") && h.lane_budget[13]) {
+        // the lane budget of the later bounces (pair path): where the wave's clocks go and how many of the 64 lanes had work there
+        const unsigned long long *B = h.lane_budget;
+        const double rounds = (double)B[13];
+        struct { const char *name; double clk, lane_clk; } ph[7] = {
+            {"load / refill", (double)B[0], (double)B[1]}, {"pre-test loop", (double)B[2], (double)B[3]}, {"full batches", (double)B[4], (double)B[4] * 64.0},
+            {"last batches", (double)B[5], (double)B[6]}, {"result", (double)B[7], (double)B[8]}, {"shade + radiance write", (double)B[9], (double)B[10]},
+            {"compaction / hand-over", (double)B[11], (double)B[12]}};
+        double tot = 0.0, tot_lane = 0.0;
+        for (auto &x : ph) { tot += x.clk; tot_lane += x.lane_clk; }
+        fprintf(stderr, "[ptamd] lane budget, later bounces: %.0f trips, %.1f rays per trip, %.0f clocks per trip; lanes with work, clock-weighted: %.1f of 64\n",
+                rounds, (double)B[14] / rounds, tot / rounds, tot_lane / tot);
+        fprintf(stderr, "[ptamd]   %-26s %10s %8s %12s %14s\n", "phase", "clocks/trip", "share", "busy lanes", "idle share");
+        for (auto &x : ph)
+            fprintf(stderr, "[ptamd]   %-26s %10.0f %7.1f%% %12.1f %13.1f%%\n", x.name, x.clk / rounds, 100.0 * x.clk / tot, x.clk > 0 ? x.lane_clk / x.clk : 0.0,
+                    100.0 * (x.clk * 64.0 - x.lane_clk) / (tot * 64.0));
+    }
     if (getenv("PT_DEBUG_PAIR") && h.dbg[4])
         fprintf(stderr, "[ptamd] pair queue: per ray %.2f sphere + %.2f box pairs; candidates that hit: %.2f + %.2f per ray; batches per wave round %.2f\n",
                 (double)h.dbg[0] / h.dbg[4], (double)h.dbg[1] / h.dbg[4], (double)h.dbg[2] / h.dbg[4], (double)h.dbg[3] / h.dbg[4], (double)h.dbg[5] / h.dbg[6]);

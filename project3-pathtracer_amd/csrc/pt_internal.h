@@ -54,6 +54,7 @@ struct IterState {
     unsigned long long clk[4];                   // diagnostics: shader-clock / real-time ticks spent by workgroup 0 of the last bounce-1 launch
     unsigned long long shadow_rays;              // shadow rays cast (direct lighting), stats
     unsigned long long dbg[8];                   // hierarchy-walk diagnostics (DEBUG_BVH builds only)
+    unsigned long long lane_budget[16];          // -DPT_DEBUG_PHASE=2 builds: clocks / lane-clocks per phase of a later-bounce trip (pair path)
 };
 
 // direct lighting: one entry of the light table -- an emissive sphere / cube (tri_count 0, prim = its index) or an emissive
