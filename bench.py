@@ -385,7 +385,10 @@ def main():
                 with open(args.traffic_json) as f:
                     ent = json.load(f).get(f"config{args.config}")
                 if ent:
-                    traffic = ent["hbm_bytes_per_launch"] / ent.get("iterations_per_launch", 16) * iters_per_launch
+                    if ent.get("hbm_bytes_per_iteration"):      # (round 4 on: per iteration, whatever the launch structure)
+                        traffic = ent["hbm_bytes_per_iteration"] * args.steps / launches_timed
+                    else:
+                        traffic = ent["hbm_bytes_per_launch"] / ent.get("iterations_per_launch", 16) * iters_per_launch
                     traffic_source = "stored: " + str(ent.get("source"))
                     flops_exec = ent.get("executed_fp32_flops_per_ray_bounce")
             except Exception:

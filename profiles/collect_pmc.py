@@ -155,6 +155,12 @@ def main():
     fetch_kb, nf = total("FETCH_SIZE")
     write_kb, nw = total("WRITE_SIZE")
     if nf and nw:
+        # per ITERATION (independent of how the bounces are cut into launches: one per bounce, or camera + one resident-path launch):
+        # every batch of a PMC pass is a full one, and the camera kernel is dispatched once per batch
+        ncam = summary["kernels"].get("k_bounce<first>", {}).get("pmc", {}).get("FETCH_SIZE", {}).get("dispatches", 0)
+        batch = (summary.get("bench_under_pmc") or {}).get("iteration_batch", 16)
+        if ncam:
+            der["hbm_bytes_per_iteration"] = ((2.0 * fetch_kb + write_kb) * 1024) / (ncam * batch)
         der["launches"] = nf
         der["fetch_bytes_per_launch_raw"] = fetch_kb * 1024 / nf
         der["write_bytes_per_launch_raw"] = write_kb * 1024 / nw
@@ -166,6 +172,10 @@ def main():
     wc, _ = total("SQ_WAVE_CYCLES")
     if valu:
         der["valu_insts"] = valu
+    for c in ("SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_SALU", "SQ_INSTS_VALU_INT32"):
+        v, _ = total(c)
+        if v:
+            der[c] = v
     if thr and act:
         der["valu_active_lanes_avg"] = thr / act      # of 64
     for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"):
@@ -197,6 +207,7 @@ def main():
     summary["k_bounce_derived"] = der
     if "hbm_bytes_per_launch" in der:
         summary["traffic_for_bench"] = {"hbm_bytes_per_launch": der["hbm_bytes_per_launch"], "iterations_per_launch": (bu or {}).get("iteration_batch", 16),
+                                        "hbm_bytes_per_iteration": der.get("hbm_bytes_per_iteration"),
                                         "executed_fp32_flops_per_ray_bounce": der.get("executed_fp32_flops_per_ray_bounce"),
                                         "source": f"pmc_{a.tag}"}
     with open(os.path.join(out, "summary.json"), "w") as f:
