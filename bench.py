@@ -223,11 +223,14 @@ def main():
         else:
             dist.barrier(device_ids=[dev_index])
 
+    # receive buffers and the frame of the gather: allocated once, here, so that nothing allocates inside the timed region
+    gbufs, gframe = sharding.gather_buffers(fb.cpu() if rehearsal else fb, Hfull, world, rank, dst=0)
+
     def gather(tile):
         fn = sharding.gather_strips if strips else sharding.gather_bands
         if rehearsal:      # gloo moves host tensors
-            return fn(tile.cpu(), Hfull, world, rank, dist=dist, dst=0)
-        return fn(tile, Hfull, world, rank, dist=dist, dst=0)       # RCCL over xGMI
+            return fn(tile.cpu(), Hfull, world, rank, dist=dist, dst=0, bufs=gbufs, frame=gframe)
+        return fn(tile, Hfull, world, rank, dist=dist, dst=0, bufs=gbufs, frame=gframe)       # RCCL over xGMI
 
     def sync():
         r.synchronize()

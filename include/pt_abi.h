@@ -137,6 +137,20 @@ typedef struct pt_options {
                              0 = library choice (default).  The image does not depend on it */
 } pt_options;
 
+/* Device memory of a context, per launch sequence in flight: two ray pools of 40 B per ray slot (batch x tile pixels slots + up
+ * to 16 % of segment slack) and the radiance planes, 16 B per (iteration in flight, pixel) -- 6.5 GB per sequence for a 1920x1080
+ * tile at batch 16, about 26 GB per sequence at the cap of 2^28 rays per launch.  The library default is two sequences; when that
+ * allocation fails the context falls back to one before pt_render reports PT_ERR_OOM.  pt_get_launch_info tells what it took.
+ *
+ * Environment variables the library reads (none changes a result; all are read when a context configures unless noted):
+ *   PT_RESIDENT=1|0, PT_SEQUENCES=n     the library's choice where pt_options.resident / .sequences leave it open (== 0) -- an
+ *                                       explicit option always wins
+ *   PT_REFILL_MIN=n                     resident paths: free lanes that trigger a wave's refill (1..64, default 8)
+ *   PT_MAX_WG_PER_CU, PT_EXTRA_LDS, PT_NO_CULL, PT_NO_EYE_CULL     launch-shape / culling ablations behind DESIGN.md's sweeps
+ *   PT_DEBUG_CLOCK, PT_DEBUG_PHASE, PT_DEBUG_PHASE2, PT_DEBUG_PAIR, PT_DEBUG_W4, PT_DEBUG_SPAN, PT_DEBUG_BOUNDS
+ *                                       print diagnostics at pt_get_stats (the counters exist in diagnostic builds only)
+ *   PT_SERIAL_BUDGET=n                  TEST HOOK (read once per process): batches a context renders before the radiance planes'
+ *                                       serial numbers start over (default 2^29) -- lets tests reach the restart */
 typedef struct pt_stats {
     unsigned long long iterations;             /* iterations rendered since create / pt_reset_stats */
     unsigned long long ray_bounces;            /* sum over iterations and bounces of live rays entering the bounce */
@@ -215,6 +229,9 @@ int  pt_render(pt_ctx *ctx, int iter_first, int iter_count);
  * tile pixels.  Asynchronous on the render stream. */
 int  pt_send_image_to_pbo(pt_ctx *ctx, pt_uchar4 *device_pbo);
 int  pt_synchronize(pt_ctx *ctx);                     /* cudaThreadSynchronize, ref: src/raytraceKernel.cu:162 */
+/* Record a caller-owned hipEvent_t on the render stream, behind everything enqueued so far: lets a host order streams of its
+ * own behind a render without waiting on the CPU (the multi-device gather does). */
+int  pt_record_event(pt_ctx *ctx, void *hip_event);
 
 /* One reference-style iteration: optional H2D of host_image_inout when iteration > 1 and the context has no
  * accumulated state, render `iteration`, optional PBO, D2H into host_image_inout (if non-NULL), synchronize. */
@@ -312,6 +329,12 @@ int  pt_multi_render(pt_multi *m, int iter_first, int iter_count);  /* asynchron
 int  pt_multi_synchronize(pt_multi *m);
 int  pt_multi_download_image(pt_multi *m, float *host_rgb_full_frame);
 int  pt_multi_gather_to_device(pt_multi *m, void *device_rgb_full_frame, int dst_device);
+/* the same, returning as soon as every device's copies are enqueued on its copy stream (behind its render stream, no host
+ * wait); pt_multi_synchronize -- or the next gather -- joins.  One gather in flight per handle. */
+int  pt_multi_gather_to_device_async(pt_multi *m, void *device_rgb_full_frame, int dst_device);
+int  pt_multi_gather_times(pt_multi *m, double *enqueue_ms, double *total_ms);   /* host clock of the last device gather */
+/* peer access between two devices as the handle found it (1 = enabled: copies cross xGMI directly, 0 = none: the runtime stages) */
+int  pt_multi_peer_access(pt_multi *m, int src_device, int dst_device, int *direct);
 int  pt_multi_set_strips(pt_multi *m, int strip_rows);   /* > 0: interleaved strips (device k: strips k, k+n, ...); 0: bands */
 int  pt_multi_send_image_to_pbo(pt_multi *m, pt_uchar4 *device_pbo);  /* single-device handles only */
 int  pt_multi_get_stats(pt_multi *m, pt_stats *out);                /* sums over devices (gpu_ms: max) */

@@ -144,6 +144,10 @@ def lib():
         "pt_bind_image": (i, [vp, vp]),
         "pt_clear_image": (i, [vp]),
         "pt_image_device_pointer": (i, [vp, P(vp)]),
+        "pt_record_event": (i, [vp, vp]),
+        "pt_multi_gather_to_device_async": (i, [vp, vp, i]),
+        "pt_multi_gather_times": (i, [vp, P(C.c_double), P(C.c_double)]),
+        "pt_multi_peer_access": (i, [vp, i, i, P(i)]),
         "pt_multi_create": (i, [P(i), i, P(vp)]),
         "pt_multi_destroy": (None, [vp]),
         "pt_multi_count": (i, [vp]),

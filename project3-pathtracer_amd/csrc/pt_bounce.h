@@ -1430,52 +1430,6 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
     for (uint32_t R = blockIdx.x; RESIDENT || R * NW < total_chunks; R += RESIDENT ? 0u : gridDim.x, ++round) {     // (dealt chunks: workgroup-uniform trip count)
         const uint32_t my_chunk = R * NW + wave;                  // dealt: round-robin over the workgroups' waves
         const unsigned long long tc0 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
-#if defined(PT_KO)
-        // sensitivity experiments (profiles/r03/knockout.txt; never in the product build): extra work that changes no result,
-        // once per 64-ray round of the later bounces -- which resource does the kernel's speed follow?
-        if (!FIRST) {
-#if PT_KO == 1      // PT_KO_N dependent v_fma_f32 (VALU issue)
-            float ko = (float)lane;
-#pragma unroll
-            for (int k = 0; k < PT_KO_N; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(ko));
-            if (ko == 12345.678f) st->dbg[7] = 1ull;
-#elif PT_KO == 2    // PT_KO_N wave-wide ds_read_b128 of one address (LDS pipe, no bank conflicts)
-            float4 ko = make_float4(0, 0, 0, 0);
-            const uint32_t ko_addr = (uint32_t)(uintptr_t)smem;
-#pragma unroll
-            for (int k = 0; k < PT_KO_N; ++k) { float4 t4; asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(t4) : "v"(ko_addr) : "memory"); ko.x += t4.x; }
-            if (ko.x == 12345.678f) st->dbg[7] = 1ull;
-#elif PT_KO == 3    // PT_KO_N x 64 cycles of sleep (pure latency: the wave issues nothing)
-#pragma unroll
-            for (int k = 0; k < PT_KO_N; ++k) __builtin_amdgcn_s_sleep(1);
-#elif PT_KO == 4    // PT_KO_N dependent s_add_u32 (scalar issue)
-            uint32_t ko = (uint32_t)wave;
-#pragma unroll
-            for (int k = 0; k < PT_KO_N; ++k) asm volatile("s_add_u32 %0, %0, 1" : "+s"(ko));
-            if (ko == 0x12345678u) st->dbg[7] = 1ull;
-#elif PT_KO == 6    // the chunk's ray records read PT_KO_N more times from the OTHER pool (same bytes, other addresses: HBM / L2 traffic)
-            {
-                Cursor kc = cur;
-                uint32_t ki;
-                float acc = 0.0f;
-                if (locate(kc, my_chunk, ki)) {
-#pragma unroll
-                    for (int k = 0; k < PT_KO_N; ++k) {
-                        const float4 a4 = out.a[ki + 64u * (uint32_t)k];
-                        const float4 b4 = out.b[ki + 64u * (uint32_t)k];
-                        acc += a4.x + b4.y;
-                    }
-                }
-                if (acc == 12345.678f) st->dbg[7] = 1ull;
-            }
-#elif PT_KO == 5    // PT_KO_N v_cndmask (4-cycle class)
-            float ko = (float)lane;
-#pragma unroll
-            for (int k = 0; k < PT_KO_N; ++k) asm volatile("v_cndmask_b32 %0, %0, %0, vcc" : "+v"(ko));
-            if (ko == 12345.678f) st->dbg[7] = 1ull;
-#endif
-        }
-#endif
         uint32_t i = 0;
         bool in_pool = false;
         if (RESIDENT) {
@@ -1903,9 +1857,6 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
             // runs priced the unconditional 12-byte store at 7-10 % of the kernel: profiles/r03/knockout.txt.)
             float4 *lp = reinterpret_cast<float4 *>(p.lbuf) + ((size_t)(pix >> SLOT_SHIFT) * npix + (size_t)(pix & PIX_MASK));
             if (!dbgInRange(p, 7, (unsigned long long)(pix >> SLOT_SHIFT) * npix + (pix & PIX_MASK), (unsigned long long)npix * st->nslot)) lp = reinterpret_cast<float4 *>(p.lbuf);
-#if defined(PT_KO) && PT_KO == 7      // (sensitivity experiment: the path's radiance sample is not written -- wrong image, same control flow)
-            if (L.x == 12345.678f)
-#endif
             nt_store((v4f){L.x, L.y, L.z, __uint_as_float(serial)}, reinterpret_cast<v4f *>(lp));
         }
 

@@ -146,6 +146,20 @@ void drop_graph(pt_ctx *c)
     }
 }
 
+// Every stream the context may have work on: the render stream and the side streams of the launch sequences.  Whoever needs the
+// context idle (configure, statistics, image copies, the error paths of pt_render after its fork) waits for all of them, so a
+// call that failed between fork and join cannot leave a side stream running against buffers the next call reuses.
+hipError_t sync_all_streams(pt_ctx *c)
+{
+    hipError_t first = hipStreamSynchronize(c->stream);
+    for (int sq = 1; sq < PT_MAX_SEQUENCES; ++sq)
+        if (c->seq_stream[sq]) {
+            const hipError_t e = hipStreamSynchronize(c->seq_stream[sq]);
+            if (first == hipSuccess) first = e;
+        }
+    return first;
+}
+
 int fold_timers(pt_ctx *c)
 {
     for (auto &t : c->timers) {
@@ -364,7 +378,7 @@ int configure(pt_ctx *c)
     if (!c->have_camera) return fail(PT_ERR_INVALID, "pt_set_camera has not been called");
     HIP_TRY(hipSetDevice(c->device));
     if (!c->dirty) return PT_OK;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(sync_all_streams(c));
     drop_graph(c);
 
     const pt_options &o = c->opt;
@@ -980,15 +994,6 @@ int configure(pt_ctx *c)
     // per-iteration radiance planes (one write per path, folded into the image by k_accumulate), per sequence
     // (16-byte entries: r, g, b and the serial number of the batch that wrote them; zeroed once -- no batch has serial 0)
     const size_t lbuf_bytes = ((size_t)nrays * 4 * sizeof(float) + 255) & ~(size_t)255;
-    if (c->lbuf_cap < lbuf_bytes * (size_t)nseq) {
-        if (c->d_lbuf) (void)hipFree(c->d_lbuf);
-        c->d_lbuf = nullptr; c->lbuf_cap = 0;
-        HIP_TRY(hipMalloc((void **)&c->d_lbuf, lbuf_bytes * (size_t)nseq));
-        c->lbuf_cap = lbuf_bytes * (size_t)nseq;
-        HIP_TRY(hipMemsetAsync(c->d_lbuf, 0, lbuf_bytes * (size_t)nseq, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
-    k.lbuf = c->d_lbuf;
 
     // Camera rays: which primitives can the 64 pixels of a bounce-0 chunk see at all?  A primitive is dropped for a span of
     // 64 tile-local pixels when its padded box lies wholly outside one of the four side planes of the span's pixel frustum
@@ -1170,12 +1175,40 @@ int configure(pt_ctx *c)
     }
     const size_t slots = (size_t)k.segcap * (size_t)k.nshard;
     const size_t one = slots * (16 + 16 + 8);
-    if (c->pool_cap < 2 * one * (size_t)nseq) {
-        if (c->d_pool) (void)hipFree(c->d_pool);
-        c->d_pool = nullptr; c->pool_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_pool, 2 * one * (size_t)nseq));
-        c->pool_cap = 2 * one * (size_t)nseq;
+    // Device memory per launch sequence: two ray pools of 40 B per slot (<= 1.16 x batch x pixels slots) and the radiance planes,
+    // 16 B per (iteration in flight, pixel) -- 6.5 GB per sequence for a 1920x1080 tile at batch 16, ~ 52 GB at the 2^28-ray cap.
+    // When the allocation for the sequences asked for fails, the context falls back to ONE sequence before it gives up.
+    for (;;) {
+        hipError_t e = hipSuccess;
+        if (c->lbuf_cap < lbuf_bytes * (size_t)nseq) {
+            if (c->d_lbuf) (void)hipFree(c->d_lbuf);
+            c->d_lbuf = nullptr; c->lbuf_cap = 0;
+            e = hipMalloc((void **)&c->d_lbuf, lbuf_bytes * (size_t)nseq);
+            if (e == hipSuccess) {
+                c->lbuf_cap = lbuf_bytes * (size_t)nseq;
+                HIP_TRY(hipMemsetAsync(c->d_lbuf, 0, c->lbuf_cap, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                // (fresh planes: the serial numbers may start over as well)
+                for (uint32_t sq = 0; sq < (uint32_t)PT_MAX_SEQUENCES; ++sq)
+                    HIP_TRY(hipMemcpy(&c->d_state[sq].serial, &sq, sizeof sq, hipMemcpyHostToDevice));
+                c->batches_stamped = 0;
+            } else c->d_lbuf = nullptr;
+        }
+        if (e == hipSuccess && c->pool_cap < 2 * one * (size_t)nseq) {
+            if (c->d_pool) (void)hipFree(c->d_pool);
+            c->d_pool = nullptr; c->pool_cap = 0;
+            e = hipMalloc(&c->d_pool, 2 * one * (size_t)nseq);
+            if (e == hipSuccess) c->pool_cap = 2 * one * (size_t)nseq;
+            else c->d_pool = nullptr;
+        }
+        if (e == hipSuccess) break;
+        (void)hipGetLastError();
+        if (nseq > 1) { nseq = 1; c->nseq = 1; continue; }      // (half the pools and planes)
+        c->dirty = true;
+        return fail(PT_ERR_OOM, "device memory: %zu B of ray pools + %zu B of radiance planes per launch sequence (%s)", 2 * one, lbuf_bytes,
+                    hipGetErrorString(e));
     }
+    k.lbuf = c->d_lbuf;
     for (int sq = 0; sq < PT_MAX_SEQUENCES; ++sq) {
         pt::KParams &ks = c->kps[sq];
         ks = k;
@@ -1190,7 +1223,6 @@ int configure(pt_ctx *c)
         ks.st = c->d_state + sq;
     }
     k = c->kps[0];
-    if (getenv("PT_PRETOUCH")) HIP_TRY(hipMemsetAsync(c->d_pool, 0, 2 * one * (size_t)nseq, c->stream));   // experiment: first touch of the pools
     if (getenv("PT_DEBUG_CLOCK")) fprintf(stderr, "[ptamd] launch sequences in flight: %d\n", nseq);
 
     c->dirty = false;
@@ -1203,6 +1235,25 @@ int configure(pt_ctx *c)
 // sq: the launch sequence (its pools, planes and IterState); with_accumulate = false leaves the accumulate to the caller,
 // who orders it behind the previous batch's.
 int bounce_launches_per_batch(const pt_ctx *c) { return c->cfg.resident ? 2 : c->kp.depth; }
+
+// Serial numbers stamp the radiance-plane entries (32 bits, + PT_MAX_SEQUENCES per batch): long before they could come round
+// again -- 2^29 batches of one context, weeks of rendering -- the planes are zeroed and the count starts over.  Every path that
+// renders batches (pt_render, the ordered batches of the motion-blur slices, pt_render_profiled) books them here first.
+// PT_SERIAL_BUDGET (environment, read once): a smaller budget, so that tests reach the restart (include/pt_abi.h, test hooks).
+int book_batch_serials(pt_ctx *c, unsigned long long nb)
+{
+    static const unsigned long long serial_budget =
+        (getenv("PT_SERIAL_BUDGET") && atoll(getenv("PT_SERIAL_BUDGET")) > 0) ? (unsigned long long)atoll(getenv("PT_SERIAL_BUDGET")) : (1ull << 29);
+    if (c->batches_stamped + nb > serial_budget) {
+        HIP_TRY(sync_all_streams(c));
+        HIP_TRY(hipMemset(c->d_lbuf, 0, c->lbuf_cap));
+        for (uint32_t sq = 0; sq < (uint32_t)PT_MAX_SEQUENCES; ++sq)
+            HIP_TRY(hipMemcpy(&c->d_state[sq].serial, &sq, sizeof sq, hipMemcpyHostToDevice));
+        c->batches_stamped = 0;
+    }
+    c->batches_stamped += nb;
+    return PT_OK;
+}
 
 int enqueue_batch(pt_ctx *c, hipStream_t s, hipEvent_t *ev, int sq = 0, bool with_accumulate = true)
 {
@@ -1292,6 +1343,8 @@ int render_batch_ordered(pt_ctx *c, hipStream_t ss, int iter_first, int count, h
     int rc = configure(c);
     if (rc != PT_OK) return rc;
     if (count < 1 || count > c->batch) return fail(PT_ERR_INVALID, "render_batch_ordered: %d iterations (batch %d)", count, c->batch);
+    rc = book_batch_serials(c, 1ull);
+    if (rc != PT_OK) return rc;
     if (c->opt.use_graph && !c->graph_exec[0]) {        // slot 0: sequence 0's batch without its accumulate (as in pt_render)
         HIP_TRY(hipStreamBeginCapture(ss, hipStreamCaptureModeThreadLocal));
         rc = enqueue_batch(c, ss, nullptr, 0, false);
@@ -1308,7 +1361,6 @@ int render_batch_ordered(pt_ctx *c, hipStream_t ss, int iter_first, int count, h
     HIP_TRY(pt::launch_accumulate(ss, ks.image, ks.lbuf, ks.st, ks.npix));
     HIP_TRY(pt::launch_iter_fold(ss, c->d_state, c->kp.depth));
     if (done_ev) HIP_TRY(hipEventRecord(done_ev, ss));
-    c->batches_stamped++;
     c->bounce_launches += (unsigned long long)bounce_launches_per_batch(c);
     c->image_valid = true;
     return PT_OK;
@@ -1409,7 +1461,7 @@ void pt_destroy(pt_ctx *c)
     if (!c) return;
     drop_slices(c);
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)sync_all_streams(c);
     drop_graph(c);
     for (auto &t : c->timers) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }
     if (c->d_prims) (void)hipFree(c->d_prims);
@@ -1568,7 +1620,7 @@ int pt_set_stream(pt_ctx *c, void *hip_stream)
 {
     if (!c) return fail(PT_ERR_INVALID, "pt_set_stream: NULL context");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(sync_all_streams(c));
     if (fold_timers(c) != PT_OK) return PT_ERR_HIP;
     drop_graph(c);
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
@@ -1686,7 +1738,7 @@ int pt_render(pt_ctx *c, int iter_first, int iter_count)
                 hipStream_t ss = (j & 1) ? c->seq_stream[1] : s;
                 rc = render_batch_ordered(c->slice_ctx[(size_t)(run % c->motion_slices)], ss, it, end - it,
                                           j > 0 ? c->seq_acc[(j - 1) & 1] : nullptr, c->seq_acc[j & 1]);
-                if (rc != PT_OK) return rc;
+                if (rc != PT_OK) { (void)sync_all_streams(c); c->image_valid = false; return rc; }      // (nothing keeps running on the second stream)
                 it = end;
             }
             if (j > 1) HIP_TRY(hipStreamWaitEvent(s, c->seq_acc[1], 0));        // join (the last event of the second stream)
@@ -1736,20 +1788,8 @@ int pt_render(pt_ctx *c, int iter_first, int iter_count)
             HIP_TRY(hipGraphInstantiate(&c->graph_exec[gs], c->graph[gs], nullptr, nullptr, 0));
         }
     }
-    // Serial numbers stamp the radiance-plane entries (32 bits, + PT_MAX_SEQUENCES per batch): long before they could come
-    // round again -- 2^29 batches of one context, weeks of rendering -- the planes are zeroed and the count starts over.
-    static const unsigned long long serial_budget =
-        (getenv("PT_SERIAL_BUDGET") && atoll(getenv("PT_SERIAL_BUDGET")) > 0) ? (unsigned long long)atoll(getenv("PT_SERIAL_BUDGET")) : (1ull << 29);   // (the override: tests)
-    if (c->batches_stamped + (unsigned long long)nb > serial_budget) {
-        HIP_TRY(hipStreamSynchronize(s));
-        for (int sq = 1; sq < PT_MAX_SEQUENCES; ++sq)
-            if (c->seq_stream[sq]) HIP_TRY(hipStreamSynchronize(c->seq_stream[sq]));
-        HIP_TRY(hipMemset(c->d_lbuf, 0, c->lbuf_cap));
-        for (uint32_t sq = 0; sq < (uint32_t)PT_MAX_SEQUENCES; ++sq)
-            HIP_TRY(hipMemcpy(&c->d_state[sq].serial, &sq, sizeof sq, hipMemcpyHostToDevice));
-        c->batches_stamped = 0;
-    }
-    c->batches_stamped += (unsigned long long)nb;
+    rc = book_batch_serials(c, (unsigned long long)nb);
+    if (rc != PT_OK) return rc;
     if (c->timers.size() >= 1024) { rc = fold_timers(c); if (rc != PT_OK) return rc; }
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreateWithFlags(&e0, hipEventDisableSystemFence));
@@ -1757,40 +1797,51 @@ int pt_render(pt_ctx *c, int iter_first, int iter_count)
     c->timers.emplace_back(e0, e1);
     HIP_TRY(hipEventRecord(e0, s));
 
-    if (nseq > 1) {
-        // fork: the other sequences start behind everything already on the render stream
-        HIP_TRY(hipEventRecord(c->seq_fork, s));
-        for (int sq = 1; sq < nseq; ++sq) HIP_TRY(hipStreamWaitEvent(c->seq_stream[sq], c->seq_fork, 0));
-    }
-    for (int sq = 0; sq < nseq; ++sq)
-        HIP_TRY(pt::launch_iter_set(c->seq_stream[sq], c->d_state + sq, (uint32_t)iter_first, (uint32_t)q, (uint32_t)r, (uint32_t)sq, (uint32_t)nseq));
-    for (int i = 0; i < nb; ++i) {
-        const int sq = i % nseq;
-        hipStream_t ss = c->seq_stream[sq];
-        if (c->opt.use_graph) {
-            const int gs = own_acc ? sq : PT_MAX_SEQUENCES;       // (a one-batch call runs on sequence 0 with its accumulate)
-            HIP_TRY(hipGraphLaunch(c->graph_exec[gs], ss));
-        } else {
-            rc = enqueue_batch(c, ss, nullptr, sq, !own_acc);
-            if (rc != PT_OK) return rc;
+    // fork ... join: a failure in between must not leave a side stream running (it would still touch the pools, the planes and
+    // the shared framebuffer while the caller reconfigures or frees them): the lambda's error returns land in the wait below
+    auto forked = [&]() -> int {
+        if (nseq > 1) {
+            // fork: the other sequences start behind everything already on the render stream
+            HIP_TRY(hipEventRecord(c->seq_fork, s));
+            for (int sq = 1; sq < nseq; ++sq) HIP_TRY(hipStreamWaitEvent(c->seq_stream[sq], c->seq_fork, 0));
         }
-        if (own_acc) {
-            // the running mean takes the batches in iteration order: batch i's accumulate behind batch i - 1's
-            if (i > 0) HIP_TRY(hipStreamWaitEvent(ss, c->seq_acc[(i - 1) % nseq], 0));
-            const pt::KParams &ks = c->kps[sq];
-            HIP_TRY(pt::launch_accumulate(ss, ks.image, ks.lbuf, ks.st, ks.npix));
-            HIP_TRY(hipEventRecord(c->seq_acc[sq], ss));
+        for (int sq = 0; sq < nseq; ++sq)
+            HIP_TRY(pt::launch_iter_set(c->seq_stream[sq], c->d_state + sq, (uint32_t)iter_first, (uint32_t)q, (uint32_t)r, (uint32_t)sq, (uint32_t)nseq));
+        for (int i = 0; i < nb; ++i) {
+            const int sq = i % nseq;
+            hipStream_t ss = c->seq_stream[sq];
+            if (c->opt.use_graph) {
+                const int gs = own_acc ? sq : PT_MAX_SEQUENCES;       // (a one-batch call runs on sequence 0 with its accumulate)
+                HIP_TRY(hipGraphLaunch(c->graph_exec[gs], ss));
+            } else {
+                const int rc2 = enqueue_batch(c, ss, nullptr, sq, !own_acc);
+                if (rc2 != PT_OK) return rc2;
+            }
+            if (own_acc) {
+                // the running mean takes the batches in iteration order: batch i's accumulate behind batch i - 1's
+                if (i > 0) HIP_TRY(hipStreamWaitEvent(ss, c->seq_acc[(i - 1) % nseq], 0));
+                const pt::KParams &ks = c->kps[sq];
+                HIP_TRY(pt::launch_accumulate(ss, ks.image, ks.lbuf, ks.st, ks.npix));
+                HIP_TRY(hipEventRecord(c->seq_acc[sq], ss));
+            }
         }
-    }
-    for (int sq = 0; sq < nseq; ++sq) HIP_TRY(pt::launch_iter_fold(c->seq_stream[sq], c->d_state + sq, c->kp.depth));
-    if (nseq > 1) {
-        // join: the render stream continues behind every sequence
-        for (int sq = 1; sq < nseq; ++sq) {
-            HIP_TRY(hipEventRecord(c->seq_acc[sq], c->seq_stream[sq]));
-            HIP_TRY(hipStreamWaitEvent(s, c->seq_acc[sq], 0));
+        for (int sq = 0; sq < nseq; ++sq) HIP_TRY(pt::launch_iter_fold(c->seq_stream[sq], c->d_state + sq, c->kp.depth));
+        if (nseq > 1) {
+            // join: the render stream continues behind every sequence
+            for (int sq = 1; sq < nseq; ++sq) {
+                HIP_TRY(hipEventRecord(c->seq_acc[sq], c->seq_stream[sq]));
+                HIP_TRY(hipStreamWaitEvent(s, c->seq_acc[sq], 0));
+            }
         }
+        HIP_TRY(hipEventRecord(e1, s));
+        return PT_OK;
+    };
+    rc = forked();
+    if (rc != PT_OK) {
+        (void)sync_all_streams(c);
+        c->image_valid = false;
+        return rc;
     }
-    HIP_TRY(hipEventRecord(e1, s));
     c->bounce_launches += (unsigned long long)nb * (unsigned long long)bounce_launches_per_batch(c);
     c->image_valid = true;
     return PT_OK;
@@ -1825,19 +1876,25 @@ int pt_render_profiled(pt_ctx *c, int iter_first, int iter_count, double *bounce
     for (int b = 0; b < depth; ++b) bounce_ms_out[b] = 0.0;
     if (iter_count == 0) return PT_OK;
     hipStream_t s = c->stream;
-    std::vector<hipEvent_t> ev((size_t)2 * (size_t)depth);
+    std::vector<hipEvent_t> ev((size_t)2 * (size_t)depth, nullptr);
+    // (every exit below destroys the events that exist)
+    struct EventGuard {
+        std::vector<hipEvent_t> &ev;
+        ~EventGuard() { for (auto &e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; } }
+    } guard{ev};
     // no system-scope fence at the events: a default event makes every kernel end with an L2 write-back and start with
     // a cold cache, which showed up as +12 % on the launches bracketed this way
     for (auto &e : ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
     int nb, q, r;
     batch_schedule(iter_count, c->batch, &nb, &q, &r);
+    rc = book_batch_serials(c, (unsigned long long)nb);
+    if (rc != PT_OK) return rc;
     HIP_TRY(pt::launch_iter_set(s, c->d_state, (uint32_t)iter_first, (uint32_t)q, (uint32_t)r, 0u, 1u));
     int launches = 0;
     for (int i = 0; i < nb; ++i) {
         rc = enqueue_batch(c, s, ev.data());
-        if (rc != PT_OK) return rc;
+        if (rc != PT_OK) { (void)hipStreamSynchronize(s); return rc; }
         launches++;
-        c->batches_stamped++;
         HIP_TRY(hipStreamSynchronize(s));
         for (int b = 0; b < bounce_launches_per_batch(c); ++b) {      // (resident paths: [1] = the one launch of all later bounces)
             float ms = 0.0f;
@@ -1847,7 +1904,6 @@ int pt_render_profiled(pt_ctx *c, int iter_first, int iter_count, double *bounce
     }
     HIP_TRY(pt::launch_iter_fold(s, c->d_state, depth));
     HIP_TRY(hipStreamSynchronize(s));
-    for (auto &e : ev) (void)hipEventDestroy(e);
     c->bounce_launches += (unsigned long long)launches * (unsigned long long)bounce_launches_per_batch(c);
     c->image_valid = true;
     return PT_OK;
@@ -1896,11 +1952,19 @@ int pt_send_image_to_pbo(pt_ctx *c, pt_uchar4 *device_pbo)
     return PT_OK;
 }
 
+int pt_record_event(pt_ctx *c, void *hip_event)
+{
+    if (!c || !hip_event) return fail(PT_ERR_INVALID, "pt_record_event: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord((hipEvent_t)hip_event, c->stream));
+    return PT_OK;
+}
+
 int pt_synchronize(pt_ctx *c)
 {
     if (!c) return fail(PT_ERR_INVALID, "pt_synchronize: NULL context");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(sync_all_streams(c));
     HIP_TRY(hipGetLastError());
     return PT_OK;
 }
@@ -1927,7 +1991,7 @@ int pt_get_stats(pt_ctx *c, pt_stats *out)
 {
     if (!c || !out) return fail(PT_ERR_INVALID, "pt_get_stats: NULL argument");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(sync_all_streams(c));
     int rc = fold_timers(c);
     if (rc != PT_OK) return rc;
     pt::IterState h;
@@ -2015,7 +2079,7 @@ int pt_reset_stats(pt_ctx *c)
 {
     if (!c) return fail(PT_ERR_INVALID, "pt_reset_stats: NULL context");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(sync_all_streams(c));
     int rc = fold_timers(c);
     if (rc != PT_OK) return rc;
     // (everything behind the header: the header holds the batch serial number, which outlives the statistics)

@@ -145,6 +145,12 @@ void cudaRaytraceCore(uchar4 *PBOpos, camera *renderCam, int frame, int iteratio
         }
         if (devs.empty()) devs.push_back(env_int("PT_DEVICE", 0));
         g.ndev = (int)devs.size();
+        // pt_options travels by pointer without a size: a library built against another header would read or miss fields
+        if (pt_abi_version() != PT_ABI_VERSION || pt_options_size() != sizeof(pt_options)) {
+            fprintf(stderr, "Cuda error: libptamd.so has ABI %d / pt_options of %zu B, this binding was built for ABI %d / %zu B.\n",
+                    pt_abi_version(), pt_options_size(), PT_ABI_VERSION, sizeof(pt_options));
+            exit(EXIT_FAILURE);
+        }
         check(pt_multi_create(devs.data(), g.ndev, &g.ctx), "pt_create");
         pt_options o;
         pt_default_options(&o);

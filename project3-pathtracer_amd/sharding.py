@@ -46,17 +46,31 @@ def max_strip_rows(height, world, strip_rows=STRIP_ROWS):
     return max(strip_local_rows(height, world, r, strip_rows) for r in range(world))
 
 
-def gather_strips(local_tile, height, world, rank, strip_rows=STRIP_ROWS, dist=None, dst=0):
+def gather_buffers(local_tile, height, world, rank, dst=0):
+    """Receive buffers and frame for gather_strips / gather_bands, allocated ONCE by the caller (bench.py: before its timed
+    region) and passed to every gather: (bufs, frame) on `dst`, (None, None) elsewhere."""
+    import torch
+    if world == 1 or rank != dst:
+        return None, None
+    bufs = [torch.empty_like(local_tile) for _ in range(world)]
+    frame = torch.empty((height,) + tuple(local_tile.shape[1:]), dtype=local_tile.dtype, device=local_tile.device)
+    return bufs, frame
+
+
+def gather_strips(local_tile, height, world, rank, strip_rows=STRIP_ROWS, dist=None, dst=0, bufs=None, frame=None):
     """Gather the per-rank strip tiles (tensors [max_strip_rows, W, 3], the first strip_local_rows rows valid) to
-    `dst` and put every row at its place in the [height, W, 3] frame.  Returns the frame on dst, None elsewhere."""
+    `dst` and put every row at its place in the [height, W, 3] frame.  Returns the frame on dst, None elsewhere.
+    bufs / frame: preallocated by gather_buffers (nothing is allocated here then)."""
     import torch
     if world == 1:
         return local_tile[:height]
-    bufs = [torch.empty_like(local_tile) for _ in range(world)] if rank == dst else None
-    dist.gather(local_tile, bufs, dst=dst)
+    if rank == dst and bufs is None:
+        bufs = [torch.empty_like(local_tile) for _ in range(world)]
+    dist.gather(local_tile, bufs if rank == dst else None, dst=dst)
     if rank != dst:
         return None
-    frame = torch.empty((height,) + tuple(local_tile.shape[1:]), dtype=local_tile.dtype, device=local_tile.device)
+    if frame is None:
+        frame = torch.empty((height,) + tuple(local_tile.shape[1:]), dtype=local_tile.dtype, device=local_tile.device)
     for r in range(world):
         rows = _strip_rows_tensor(height, world, r, strip_rows, local_tile.device)
         frame.index_copy_(0, rows, bufs[r][: rows.numel()])
@@ -99,20 +113,23 @@ def scaled_frame(width, height, world, scaling="weak"):
     return weak_scaled_frame(width, height, world)
 
 
-def gather_bands(local_band, height, world, rank, dist=None, dst=0):
+def gather_bands(local_band, height, world, rank, dist=None, dst=0, bufs=None, frame=None):
     """Gather the per-rank bands (tensors [max_band_rows, W, 3], only the first rows of each are valid) to
     `dst` and assemble the [height, W, 3] frame there.  Returns the frame on dst, None elsewhere.
-    `dist` is torch.distributed (any backend: nccl on GPUs, gloo in the CPU tests)."""
+    `dist` is torch.distributed (any backend: nccl on GPUs, gloo in the CPU tests).
+    bufs / frame: preallocated by gather_buffers (nothing is allocated here then)."""
     import torch
     if world == 1:
         r0, r1 = band_rows(height, 1, 0)
         return local_band[: r1 - r0]
-    bufs = [torch.empty_like(local_band) for _ in range(world)] if rank == dst else None
-    dist.gather(local_band, bufs, dst=dst)
+    if rank == dst and bufs is None:
+        bufs = [torch.empty_like(local_band) for _ in range(world)]
+    dist.gather(local_band, bufs if rank == dst else None, dst=dst)
     if rank != dst:
         return None
-    parts = []
+    if frame is None:
+        frame = torch.empty((height,) + tuple(local_band.shape[1:]), dtype=local_band.dtype, device=local_band.device)
     for r in range(world):
         r0, r1 = band_rows(height, world, r)
-        parts.append(bufs[r][: r1 - r0])
-    return torch.cat(parts, dim=0)
+        frame[r0:r1].copy_(bufs[r][: r1 - r0])
+    return frame

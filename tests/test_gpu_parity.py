@@ -223,6 +223,53 @@ with pkg.Renderer(0) as r:
     assert np.array_equal(g.view(np.uint32), c.view(np.uint32))
 
 
+def test_radiance_plane_serials_start_over_on_every_path(pkg, tmp_path):
+    """The same restart on the two other paths that render batches: the ordered batches of the motion-blur slice contexts (two
+    streams) and pt_render_profiled.  PT_SERIAL_BUDGET=2 in a child process: 3 slices x several runs of 16 iterations, then a
+    profiled render on a static scene -- both must match the oracle bit for bit."""
+    import subprocess
+    code = """
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'tests'))
+import numpy as np
+from __graft_entry__ import load_package
+pkg = load_package()
+path = os.path.join({root!r}, 'scenes', 'sampleScene_anim.txt')
+a, b = pkg.SceneFile(path, 1, frame=0), pkg.SceneFile(path, 1, frame=1)
+a.set_resolution(64, 48)
+with pkg.Renderer(0) as r:
+    r.set_options(depth=4)
+    r.set_scene(a.geoms, a.n_objects, a.mats, a.n_materials)
+    r.set_camera(a.camera)
+    r.set_motion(b.geoms, b.camera, 3, pkg.ROTAT_DEGREES)
+    r.clear_image()
+    for k in range(6):                      # 6 x 32 iterations: every slice context renders four runs of 16
+        r.render(1 + 32 * k, 32)
+    np.save(sys.argv[1], r.download_image())
+sc = pkg.SceneFile(os.path.join({root!r}, 'scenes', 'sampleScene_spec.txt'))
+sc.set_resolution(64, 48)
+with pkg.Renderer(0) as r:
+    r.set_options(depth=4, batch=2)
+    r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
+    r.set_camera(sc.camera)
+    r.clear_image()
+    for k in range(5):
+        r.render_profiled(1 + 2 * k, 2)
+    np.save(sys.argv[2], r.download_image())
+""".format(root=ROOT)
+    p1, p2 = str(tmp_path / "slices.npy"), str(tmp_path / "profiled.npy")
+    res = subprocess.run([sys.executable, "-c", code, p1, p2], env=dict(os.environ, PT_SERIAL_BUDGET="2"), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    path = os.path.join(SCENES, "sampleScene_anim.txt")
+    oa, ob = O.LoadedScene(path, 1, frame=0), O.LoadedScene(path, 1, frame=1)
+    oa.set_resolution(64, 48)
+    sg, scm = O.motion_slices(oa.geoms, ob.geoms, oa.n_objects, oa.camera, ob.camera, 3, O.ROTAT_DEGREES)
+    c1, _ = O.render(oa.geoms, oa.n_objects, oa.mats, oa.n_materials, oa.camera, 4, iters=192, slice_geoms=sg, slice_cams=scm)
+    assert np.array_equal(np.load(p1).view(np.uint32), c1.view(np.uint32))
+    c2, _ = cpu_render("sampleScene_spec.txt", 64, 48, 4, iters=10)
+    assert np.array_equal(np.load(p2).view(np.uint32), c2.view(np.uint32))
+
+
 def test_launch_sequences_across_calls_and_features(pkg):
     """Two sequences in flight over several pt_render calls (resume), with direct lighting (planes accumulate along the
     path) and on the batched walk: same bits as the oracle."""
@@ -819,6 +866,59 @@ def test_multi_device_handle_with_strips(pkg, ndev, strip):
         assert L.pt_multi_render(m, iters + 1, 2) == 0
         assert L.pt_multi_download_image(m, host.ctypes.data) == 0
         assert np.array_equal(host, ref4)
+    finally:
+        L.pt_multi_destroy(m)
+
+
+@pytest.mark.parametrize("strip", [0, 8])
+def test_multi_device_gather_is_enqueued_not_awaited(pkg, strip):
+    """pt_multi_gather_to_device_async on a 3840x2160 frame cut into 8 tiles (bands, and 8-row strips as the shim uses them):
+    the call orders each device's copy stream behind its render stream with an event and returns when the copies are ENQUEUED
+    -- while the render it depends on is still running -- and pt_multi_synchronize is the one join.  The frame that arrives is the
+    single-context frame; the handle reports peer access for every pair (same device: direct) and the gather's host times."""
+    import time
+    import torch
+    L = pkg.lib()
+    W, H, depth, iters, ndev = 3840, 2160, 3, 16, 8
+    sc = pkg.SceneFile(os.path.join(SCENES, "sampleScene_spec.txt"))
+    sc.set_resolution(W, H)
+    ref, _, _ = gpu_render(pkg, "sampleScene_spec.txt", W, H, depth, iters=iters)
+    devs = (C.c_int * ndev)(*([0] * ndev))
+    m = C.c_void_p()
+    assert L.pt_multi_create(devs, ndev, C.byref(m)) == 0
+    try:
+        o = pkg.Options()
+        L.pt_default_options(C.byref(o))
+        o.depth = depth
+        assert L.pt_multi_set_options(m, C.byref(o)) == 0
+        assert L.pt_multi_set_strips(m, strip) == 0
+        assert L.pt_multi_set_scene(m, sc.geoms, sc.n_objects, sc.mats, sc.n_materials) == 0
+        assert L.pt_multi_set_camera(m, C.byref(sc.camera)) == 0
+        assert L.pt_multi_clear_image(m) == 0
+        assert L.pt_multi_render(m, 1, 1) == 0            # (graphs captured, pools allocated)
+        assert L.pt_multi_synchronize(m) == 0
+        assert L.pt_multi_clear_image(m) == 0
+        dev = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        assert L.pt_multi_render(m, 1, iters) == 0         # ~ 10 ms of GPU work, enqueued in well under a millisecond
+        assert L.pt_multi_gather_to_device_async(m, dev.data_ptr(), 0) == 0
+        t_enq = time.perf_counter() - t0
+        assert L.pt_multi_synchronize(m) == 0
+        t_all = time.perf_counter() - t0
+        enq, tot = C.c_double(), C.c_double()
+        assert L.pt_multi_gather_times(m, C.byref(enq), C.byref(tot)) == 0
+        print(f"strips={strip}: render + gather enqueued in {t_enq * 1e3:.2f} ms, done after {t_all * 1e3:.2f} ms; gather enqueue {enq.value:.3f} ms, joined after {tot.value:.2f} ms")
+        assert np.array_equal(dev.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+        # the gather call came back long before the render it waits for had finished: it waited for nothing on the host
+        assert t_enq < 0.5 * t_all and enq.value < 0.5 * tot.value, (t_enq, t_all, enq.value, tot.value)
+        d = C.c_int(-1)
+        assert L.pt_multi_peer_access(m, 0, 0, C.byref(d)) == 0 and d.value == 1
+        # a second gather while nothing renders, the plain (joining) form
+        dev.zero_()
+        torch.cuda.synchronize()
+        assert L.pt_multi_gather_to_device(m, dev.data_ptr(), 0) == 0
+        assert np.array_equal(dev.cpu().numpy().view(np.uint32), ref.view(np.uint32))
     finally:
         L.pt_multi_destroy(m)
 
