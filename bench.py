@@ -378,6 +378,21 @@ def main():
         p_bytes = pkg.algorithmic_bytes(npix, p_live, prof_steps)
         p_ms = sum(bounce_ms)
         p_launches = int(pst.bounce_launches)
+        # the profiled batch kernel by kernel: algorithmic bytes of the bounces a launch traces (generate + the records its bounces
+        # read and write + the pixel read-modify-write of the paths that END in it) over its own event time
+        per_kernel = []
+        first_b = list(range(args.depth)) if not li.resident else [0, 1]
+        for k, b0 in enumerate(first_b):
+            b1 = (b0 + 1) if (not li.resident or b0 == 0) else args.depth          # bounces [b0, b1) run in this launch
+            nxt = lambda b: p_live[b] if b < args.depth else 0
+            kb = sum((p_live[b] + nxt(b + 1)) * 40 for b in range(b0, b1)) + (p_live[b0] - nxt(b1)) * 24
+            if b0 == 0:
+                kb += prof_steps * npix * 40
+            ms = bounce_ms[k]
+            per_kernel.append({"kernel": "k_bounce<FIRST> (camera + bounce 0)" if b0 == 0 else
+                               (f"k_bounce<RESIDENT> (bounces 1..{args.depth - 1})" if li.resident else f"k_bounce (bounce {b0})"),
+                               "ms": ms, "bytes": kb, "achieved": kb / (ms * 1e-3) / 1e9 if ms > 0 else None,
+                               "frac": kb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None})
         # HBM bytes from the PMC counters cannot be collected inside this run (rocprofv3 --pmc, one pass per counter
         # group): the figure is the STORED result of the last collection for this config (profiles/collect_pmc.py), kept
         # per iteration-bounce and scaled to the iterations one launch of THIS run carries
@@ -443,7 +458,7 @@ def main():
             "algorithmic_GBs_whole_job": alg_bytes / dt_max / 1e9,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "pt::k_bounce",
+                "kernel": "pt::k_bounce (resident-path instance: bounces 1..depth-1 in one launch; camera instance: bounce 0)" if li.resident else "pt::k_bounce",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -458,6 +473,7 @@ def main():
                 "kernel_alone": {"avg_launch_ms": p_ms / p_launches, "bytes_per_launch": p_bytes / p_launches,
                                  "achieved": p_bytes / (p_ms * 1e-3) / 1e9, "frac": p_bytes / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  "launches_measured": p_launches,
+                                 "per_kernel": per_kernel if (li.resident or args.depth <= 8) else per_kernel[:2] + per_kernel[-1:],
                                  "how": "one sequence, eager launches, one HIP event pair per launch (pt_render_profiled)"},
                 "note": "achieved = algorithmic bytes of the timed region's k_bounce launches (SURVEY 8(d): P*40 + "
                         "sum_b(live_in+live_out)*40 + P*24 per iteration) / HIP-event time of the timed region on the render "

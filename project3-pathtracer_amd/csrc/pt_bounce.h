@@ -34,6 +34,8 @@ static constexpr bool DEBUG_PAIR = PT_DEBUG_PAIR != 0;
 static constexpr bool DEBUG_PHASE = PT_DEBUG_PHASE == 1;     // per-wave shader-clock stamps between the phases of a chunk -> IterState::dbg
 static constexpr bool DEBUG_PHASE2 = PT_DEBUG_PHASE == 2;    // finer split of the later bounces (pair-queue path): load, pre-test loop
                                                              // + full batches, last batches, result, RNG, lobe + radiance write, compaction
+// the lane budget (clocks and busy lanes per phase of a trip, pair path): -DPT_DEBUG_PHASE=2 books the later bounces, =3 the camera launch
+template <bool FIRST> __device__ __forceinline__ constexpr bool LANE_BUDGET() { return FIRST ? PT_DEBUG_PHASE == 3 : PT_DEBUG_PHASE == 2; }
 static constexpr bool DEBUG_BVH = PT_DEBUG_BVH != 0;         // count node / leaf visits of the hierarchy walk into IterState::dbg
 static constexpr int MAXSLOT = 16;                // iterations in flight per launch sequence (pt_internal.h PT_MAX_BATCH)
 static constexpr uint32_t SLOT_SHIFT = 27;        // pixel word = tile-local pixel | slot << 27 | NEE mark << 31
@@ -627,7 +629,7 @@ template <bool FIRST, class PR, bool MOTION = false>
 __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_prims, const float4 *s_boxes, const PairQueue q,
                                                f3 o, f3 d, bool valid, uint32_t lane, uint32_t primmask, MotionTime mymt = MotionTime())
 {
-    const unsigned long long ph_in = (DEBUG_PHASE2 && !FIRST) ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long ph_in = LANE_BUDGET<FIRST>() ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long fb_clk = 0ull, lb_lane_clk = 0ull;      // DEBUG_PHASE2: clocks inside full batches; lane-clocks of the last batches
     q.key[lane] = KEY_NONE;
     q.org[lane] = make_float4(o.x, o.y, o.z, d.x);
@@ -667,17 +669,17 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
             if (pass) q.q[0][(tail[0] + rank) & (QCAP - 1u)] = lane | ((uint32_t)g << 8);
             tail[0] += (uint32_t)__popcll(mask);
             if (tail[0] - head[0] >= 64u) {
-                const unsigned long long tb = (DEBUG_PHASE2 && !FIRST) ? __builtin_amdgcn_s_memtime() : 0ull;
+                const unsigned long long tb = LANE_BUDGET<FIRST>() ? __builtin_amdgcn_s_memtime() : 0ull;
                 pairBatch<0u, FIRST, PR, MOTION>(p, s_prims, q, head[0], 64u, lane); head[0] += 64u;
-                if (DEBUG_PHASE2 && !FIRST) fb_clk += __builtin_amdgcn_s_memtime() - tb;
+                if (LANE_BUDGET<FIRST>()) fb_clk += __builtin_amdgcn_s_memtime() - tb;
             }
         } else {
             if (pass) q.q[1][(tail[1] + rank) & (QCAP - 1u)] = lane | ((uint32_t)g << 8);
             tail[1] += (uint32_t)__popcll(mask);
             if (tail[1] - head[1] >= 64u) {
-                const unsigned long long tb = (DEBUG_PHASE2 && !FIRST) ? __builtin_amdgcn_s_memtime() : 0ull;
+                const unsigned long long tb = LANE_BUDGET<FIRST>() ? __builtin_amdgcn_s_memtime() : 0ull;
                 pairBatch<1u, FIRST, PR, MOTION>(p, s_prims, q, head[1], 64u, lane); head[1] += 64u;
-                if (DEBUG_PHASE2 && !FIRST) fb_clk += __builtin_amdgcn_s_memtime() - tb;
+                if (LANE_BUDGET<FIRST>()) fb_clk += __builtin_amdgcn_s_memtime() - tb;
             }
         }
     }
@@ -689,21 +691,21 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
         atomicAdd(&p.st->dbg[5], (unsigned long long)((tail[0] + 63) / 64 + (tail[1] + 63) / 64));
         atomicAdd(&p.st->dbg[6], 1ull);
     }
-    const unsigned long long ph_a = (DEBUG_PHASE2 && !FIRST) ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long ph_a = LANE_BUDGET<FIRST>() ? __builtin_amdgcn_s_memtime() : 0ull;
     const uint32_t left0 = tail[0] - head[0], left1 = tail[1] - head[1];      // both < 64
     if (left0 != 0u && left1 != 0u && left0 + left1 <= 64u) {
         pairBatch<2u, FIRST, PR, MOTION>(p, s_prims, q, head[0], left0, lane, head[1], left1);   // one mixed batch instead of two partial ones
-        if (DEBUG_PHASE2 && !FIRST) lb_lane_clk += (__builtin_amdgcn_s_memtime() - ph_a) * (unsigned long long)(left0 + left1);
+        if (LANE_BUDGET<FIRST>()) lb_lane_clk += (__builtin_amdgcn_s_memtime() - ph_a) * (unsigned long long)(left0 + left1);
     } else {
         if (left0 != 0u) pairBatch<0u, FIRST, PR, MOTION>(p, s_prims, q, head[0], left0, lane);
-        const unsigned long long ph_b = (DEBUG_PHASE2 && !FIRST) ? __builtin_amdgcn_s_memtime() : 0ull;
-        if (DEBUG_PHASE2 && !FIRST) lb_lane_clk += (ph_b - ph_a) * (unsigned long long)left0;
+        const unsigned long long ph_b = LANE_BUDGET<FIRST>() ? __builtin_amdgcn_s_memtime() : 0ull;
+        if (LANE_BUDGET<FIRST>()) lb_lane_clk += (ph_b - ph_a) * (unsigned long long)left0;
         if (left1 != 0u) pairBatch<1u, FIRST, PR, MOTION>(p, s_prims, q, head[1], left1, lane);
-        if (DEBUG_PHASE2 && !FIRST) lb_lane_clk += (__builtin_amdgcn_s_memtime() - ph_b) * (unsigned long long)left1;
+        if (LANE_BUDGET<FIRST>()) lb_lane_clk += (__builtin_amdgcn_s_memtime() - ph_b) * (unsigned long long)left1;
     }
     wave_lds_fence();
     Hit h;
-    if (DEBUG_PHASE2 && !FIRST) {
+    if (LANE_BUDGET<FIRST>()) {
         h.dbg0 = ph_a - ph_in - fb_clk;                        // the pre-test loop without the full batches it ran
         h.dbg1 = __builtin_amdgcn_s_memtime() - ph_a;
         h.dbg2 = fb_clk;
@@ -1429,7 +1431,7 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
     uint32_t lb = (uint32_t)bounce;                  // the bounce this lane's path is at (RESIDENT: per lane)
     for (uint32_t R = blockIdx.x; RESIDENT || R * NW < total_chunks; R += RESIDENT ? 0u : gridDim.x, ++round) {     // (dealt chunks: workgroup-uniform trip count)
         const uint32_t my_chunk = R * NW + wave;                  // dealt: round-robin over the workgroups' waves
-        const unsigned long long tc0 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long tc0 = (DEBUG_PHASE || PT_DEBUG_PHASE == 2 || PT_DEBUG_PHASE == 3) ? __builtin_amdgcn_s_memtime() : 0ull;
         uint32_t i = 0;
         bool in_pool = false;
         if (RESIDENT) {
@@ -1571,7 +1573,7 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
         if (COMPACT == 0) live_count += (uint32_t)__popcll(__ballot(valid));
 
         bool alive = false;
-        const unsigned long long c1 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long c1 = (DEBUG_PHASE || PT_DEBUG_PHASE == 2 || PT_DEBUG_PHASE == 3) ? __builtin_amdgcn_s_memtime() : 0ull;
         // camera rays share the eye (host-side eye transforms and eye-relative boxes) unless a lens spreads their origins
         // camera rays of the pair path: which primitives the chunk's 64 pixels can see (host-built table, one word per span
         // of 64 tile-local pixels, no lens).  A chunk is one span when npix % 64 == 0; else it lies across two of them
@@ -1604,8 +1606,8 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
             h = (FIRST && p.lens_radius > 0.0f) ? nearestHit<GEOM, false>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane)
                                                 : nearestHit<GEOM, FIRST>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane, primmask);
         }
-        const unsigned long long c2 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
-        if (DEBUG_PHASE2 && !FIRST) { lb_nvalid = (uint32_t)__popcll(__ballot(valid)); lb_nhit = (uint32_t)__popcll(__ballot(valid && h.any)); }
+        const unsigned long long c2 = (DEBUG_PHASE || PT_DEBUG_PHASE == 2 || PT_DEBUG_PHASE == 3) ? __builtin_amdgcn_s_memtime() : 0ull;
+        if (LANE_BUDGET<FIRST>()) { lb_nvalid = (uint32_t)__popcll(__ballot(valid)); lb_nhit = (uint32_t)__popcll(__ballot(valid && h.any)); }
         bool did_bsdf = false;            // (DEBUG_PHASE2)
         f3 L = mk(0, 0, 0);               // radiance this vertex adds to the path's sample
         // direct lighting: the shadow ray this lane wants traced and what it is worth if the light is visible
@@ -1860,10 +1862,10 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
             nt_store((v4f){L.x, L.y, L.z, __uint_as_float(serial)}, reinterpret_cast<v4f *>(lp));
         }
 
-        const unsigned long long c3 = (DEBUG_PHASE || DEBUG_PHASE2) ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long c3 = (DEBUG_PHASE || PT_DEBUG_PHASE == 2 || PT_DEBUG_PHASE == 3) ? __builtin_amdgcn_s_memtime() : 0ull;
         if (DEBUG_PHASE) { ph[0] += c1 - tc0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[4] += 1; }
-        if (DEBUG_PHASE2 && !FIRST) { ph[0] += c1 - tc0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[4] += 1; ph5 += h.dbg0 + h.dbg2; ph6 += h.dbg1; }
-        if (DEBUG_PHASE2 && !FIRST && GEOM == GEOM_PAIR) {
+        if (LANE_BUDGET<FIRST>()) { ph[0] += c1 - tc0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[4] += 1; ph5 += h.dbg0 + h.dbg2; ph6 += h.dbg1; }
+        if (LANE_BUDGET<FIRST>() && GEOM == GEOM_PAIR) {
             lb_nbsdf = (uint32_t)__popcll(__ballot(did_bsdf));
             const unsigned long long res = (c2 - c1) - h.dbg0 - h.dbg1 - h.dbg2;
             lbud[0] += c1 - tc0;  lbud[1] += (c1 - tc0) * lb_nvalid;          // load / refill
@@ -1934,7 +1936,7 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
                 }
             }
         }
-        if (DEBUG_PHASE2 && !FIRST) {
+        if (LANE_BUDGET<FIRST>()) {
             const unsigned long long c4 = __builtin_amdgcn_s_memtime() - c3;
             ph[3] += c4;
             if (GEOM == GEOM_PAIR) { lbud[11] += c4; lbud[12] += c4 * (unsigned long long)__popcll(__ballot(alive)); }      // compaction + pool write
@@ -1955,11 +1957,11 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
     if (NEE) {
         if (lane == 0 && shadow_count) atomicAdd(&st->shadow_rays, (unsigned long long)shadow_count);
     }
-    if (DEBUG_PHASE2 && !FIRST && GEOM == GEOM_PAIR && lane == 0) {
+    if (LANE_BUDGET<FIRST>() && GEOM == GEOM_PAIR && lane == 0) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) atomicAdd(&st->lane_budget[k], lbud[k]);
     }
-    if (DEBUG_PHASE2 && !FIRST && lane == 0) {
+    if (LANE_BUDGET<FIRST>() && lane == 0) {
         atomicAdd(&st->dbg[1], ph5);
         atomicAdd(&st->dbg[2], ph6);
         atomicAdd(&st->dbg[0], ph[0]);       // load
