@@ -134,7 +134,7 @@ typedef struct pt_options {
                              paths that go on, refills the lanes of those that ended from the camera launch's ray pool): 1 = on
                              where a kernel exists for the launch shape (pair queue and batched walks, i.e. geom_path 0 / 5 / 7 / 8,
                              without direct_light / scatter / motion_per_ray, depth >= 3), -1 = off (one launch per bounce),
-                             0 = library choice (default).  The image does not depend on it */
+                             0 = library choice (default: on from depth 5 on, where it pays).  The image does not depend on it */
 } pt_options;
 
 /* Device memory of a context, per launch sequence in flight: two ray pools of 40 B per ray slot (batch x tile pixels slots + up

@@ -540,6 +540,11 @@ struct PairQueue {
     unsigned long long *dbg;
 };
 static constexpr uint32_t PAIR_QUEUE_BYTES = 2 * QCAP * 4 + 64 * 8 + 2 * 64 * 16 + 64 * 8;
+// LDS bytes per primitive of the pre-test's box table: eight (near, far) entries, one per direction octant (-DPT_PRETEST_OCT=0: lo, hi)
+#ifndef PT_PRETEST_OCT
+#define PT_PRETEST_OCT 1
+#endif
+static constexpr int PAIR_BOX_BYTES = PT_PRETEST_OCT ? 256 : 32;
 static constexpr uint32_t PAIR_QUEUE_MOTION_BYTES = PAIR_QUEUE_BYTES + 64 * 8;      // + the owners' shutter times
 static_assert(PAIR_QUEUE_BYTES <= WAVE_QUEUE_BYTES, "the pair queue lives in the hit queue's LDS region");
 
@@ -641,6 +646,10 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
     // slab distances as fma(plane, 1/d, -o/d): one instruction per plane; against (plane - o)/d this moves a plane by
     // less than 1.2e-6 |o|, far inside the boxes' padding
     const f3 oinv = FIRST ? mk(0, 0, 0) : mk(-(o.x * dinv.x), -(o.y * dinv.y), -(o.z * dinv.z));
+#if PT_PRETEST_OCT
+    // the ray's direction octant as an offset (in float4) into a primitive's eight (near, far) entries
+    const uint32_t octoff = ((__float_as_uint(dinv.x) >> 31) | ((__float_as_uint(dinv.y) >> 31) << 1) | ((__float_as_uint(dinv.z) >> 31) << 2)) * 2u;
+#endif
     for (int g = 0; g < p.nG; ++g) {
         // camera rays: the host's table says which primitives the 64 pixels of this chunk can see at all (primmask, bit g;
         // all ones without a table).  The bounds-checking build runs the test anyway and reports a pair that passes.
@@ -652,6 +661,17 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
         if (type > 1u) continue;                             // MESH: never has geometry
         // padded world box of the primitive against this lane's ray (camera rays: box relative to the shared eye), through
         // an LDS broadcast read: VGPR operands keep the six fma at the full VALU rate (SGPR operands halve it)
+#if PT_PRETEST_OCT
+        // near and far planes picked by ADDRESS: the LDS table holds every box once per direction octant as (near.xyz, far.xyz), so
+        // the slab test needs no min / max per axis (6 VALU per primitive and trip less).  Same tn / tf bit for bit: fma is monotonic
+        // in the plane, so for 1/d > 0 the lo plane IS the smaller product.  The eight 32-byte entries of a primitive cover all 64
+        // banks once: lanes of different octants never meet on a bank.
+        const float4 n4 = s_boxes[16 * g + octoff], f4 = s_boxes[16 * g + octoff + 1];
+        const float tn = fmaxf(fmaxf(__builtin_fmaf(n4.x, dinv.x, oinv.x), __builtin_fmaf(n4.y, dinv.y, oinv.y)),
+                               fmaxf(__builtin_fmaf(n4.z, dinv.z, oinv.z), 0.0f));
+        const float tf = fminf(fminf(__builtin_fmaf(f4.x, dinv.x, oinv.x), __builtin_fmaf(f4.y, dinv.y, oinv.y)),
+                               __builtin_fmaf(f4.z, dinv.z, oinv.z));
+#else
         const float4 lo4 = s_boxes[2 * g], hi4 = s_boxes[2 * g + 1];
         const f3 lo = mk(lo4.x, lo4.y, lo4.z), hi = mk(hi4.x, hi4.y, hi4.z);
         const float x0 = __builtin_fmaf(lo.x, dinv.x, oinv.x), x1 = __builtin_fmaf(hi.x, dinv.x, oinv.x);
@@ -659,6 +679,7 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
         const float z0 = __builtin_fmaf(lo.z, dinv.z, oinv.z), z1 = __builtin_fmaf(hi.z, dinv.z, oinv.z);
         const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
         const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+#endif
         // the compare's lane mask straight from v_cmp, and back into a predicate without VALU work
         const uint64_t mask = __builtin_amdgcn_fcmpf(tn, tf, FCMP_OLE) & vmask;
         if (mask == 0ull) continue;
@@ -1228,7 +1249,7 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
     // pair queue: the same region holds the primitives' padded boxes (2 float4 each; relative to the eye for camera rays)
     const int node_bytes = (GEOM == GEOM_BVH || GEOM == GEOM_WALK_PAIR) ? p.nnodes * (int)sizeof(BvhNode)
                            : (GEOM == GEOM_WALK4 ? ((p.nnodes4 * W4_FLOATS * 4 + 127) & ~127)
-                                                 : (GEOM == GEOM_PAIR ? p.nG * 32 * (NEE ? 2 : 1) : 0));
+                                                 : (GEOM == GEOM_PAIR ? p.nG * PAIR_BOX_BYTES * (NEE ? 2 : 1) : 0));
     unsigned char *s_queue = smem + prim_bytes + node_bytes;
     const int WAVE_LDS = (GEOM == GEOM_QUEUE) ? (int)WAVE_QUEUE_BYTES
                          : ((GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR) ? (int)((MOTION && GEOM == GEOM_PAIR) ? PAIR_QUEUE_MOTION_BYTES : PAIR_QUEUE_BYTES)
@@ -1265,11 +1286,25 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
         // (FEAT_MOTION: box_world holds the boxes swept over the shutter interval, and camera rays have no common eye)
         const uint4 *src = reinterpret_cast<const uint4 *>((FIRST && !MOTION && !(p.lens_radius > 0.0f)) ? p.box_eye : p.box_world);
         uint4 *dst = reinterpret_cast<uint4 *>(smem + prim_bytes);
+#if PT_PRETEST_OCT
+        // per primitive eight entries (near.xyz, far.xyz), one per direction octant (bit 0 / 1 / 2 = the ray runs towards -x / -y / -z)
+        auto stage_oct = [&](const uint4 *from, uint4 *to) {
+            for (int k = tid; k < p.nG * 8; k += WG) {
+                const uint4 lo = from[2 * (k >> 3)], hi = from[2 * (k >> 3) + 1];
+                const int oc = k & 7;
+                to[2 * k] = make_uint4((oc & 1) ? hi.x : lo.x, (oc & 2) ? hi.y : lo.y, (oc & 4) ? hi.z : lo.z, 0u);
+                to[2 * k + 1] = make_uint4((oc & 1) ? lo.x : hi.x, (oc & 2) ? lo.y : hi.y, (oc & 4) ? lo.z : hi.z, 0u);
+            }
+        };
+        stage_oct(src, dst);
+        if (NEE) stage_oct(reinterpret_cast<const uint4 *>(p.box_world), dst + p.nG * 16);      // shadow rays start anywhere: world boxes, second half
+#else
         for (int k = tid; k < p.nG * 2; k += WG) dst[k] = src[k];
         if (NEE) {                                           // shadow rays start anywhere: world boxes, second half
             const uint4 *srcw = reinterpret_cast<const uint4 *>(p.box_world);
             for (int k = tid; k < p.nG * 2; k += WG) dst[p.nG * 2 + k] = srcw[k];
         }
+#endif
     }
     if (GEOM == GEOM_BVH || GEOM == GEOM_WALK_PAIR) {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.bvh);
@@ -1831,12 +1866,12 @@ __global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_W
                 shadow_count += (uint32_t)__popcll(wmask);
                 Hit hs;
                 if (MOTION && GEOM == GEOM_PAIR) {
-                    hs = nearestHit<GEOM, false, true>(p, s_prims, s_nodes + 2 * p.nG, wq, so, sd, want_shadow, (uint32_t)lane, 0xFFFFFFFFu, mt);
+                    hs = nearestHit<GEOM, false, true>(p, s_prims, s_nodes + (PAIR_BOX_BYTES / 16) * p.nG, wq, so, sd, want_shadow, (uint32_t)lane, 0xFFFFFFFFu, mt);
                 } else if (MOTION) {
                     hs.any = false; hs.material = 0; hs.prim = 0; hs.t = 0.0f; hs.p = mk(0, 0, 0); hs.n = mk(0, 0, 0);
                     if (want_shadow) hs = nearestHitMotion(p, so, sd, mt);
                 } else {
-                    hs = nearestHit<GEOM, false>(p, s_prims, (GEOM == GEOM_PAIR) ? s_nodes + 2 * p.nG : s_nodes, wq, so, sd, want_shadow, (uint32_t)lane);
+                    hs = nearestHit<GEOM, false>(p, s_prims, (GEOM == GEOM_PAIR) ? s_nodes + (PAIR_BOX_BYTES / 16) * p.nG : s_nodes, wq, so, sd, want_shadow, (uint32_t)lane);
                 }
                 if (want_shadow && hs.any && hs.prim == lprim) {
                     const float tol = 1e-3f * ((ldist > 1.0f) ? ldist : 1.0f);

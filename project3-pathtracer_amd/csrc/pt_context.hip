@@ -907,9 +907,13 @@ int configure(pt_ctx *c)
     {
         int want = o.resident;
         if (want == 0 && getenv("PT_RESIDENT")) want = atoi(getenv("PT_RESIDENT")) > 0 ? 1 : -1;      // (only when the option leaves the choice open)
+        // Library choice: from 5 bounces on.  The one launch saves depth - 2 launches and their tails and pays with a drain (the last
+        // paths of every wave run up to depth - 1 trips alone): 1920x1080: - 5 % / +- 0 / + 4 % / + 4 % at depth 3 / 4 / 5 / 6;
+        // 400x400: - 13 % / - 4 % / + 1 % / + 3 % (profiles/r04/ab_resident_paths.txt).  An explicit 1 takes it from 3 bounces on.
+        const int min_depth = (want == 0) ? 5 : 3;
         if (want == 0) want = PT_RESIDENT_DEFAULT;
         cfg.resident = 0;
-        if (want > 0 && k.depth >= 3) {
+        if (want > 0 && k.depth >= min_depth) {
             pt::LaunchCfg t = cfg;
             if ((t.geom == 6 || t.geom == 7) && o.workgroup == 0) t.workgroup = 512;     // (the walks pick 256 or 512 below: both exist)
             cfg.resident = pt::bounce_resident_available(t) ? 1 : 0;

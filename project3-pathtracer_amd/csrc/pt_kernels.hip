@@ -264,7 +264,7 @@ size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg)
                                                       : ((cfg.geom == GEOM_WALK4 || cfg.geom == GEOM_WALK4G) ? walk4_wave_bytes(p.ntri) : 0)));
     if (cfg.geom == GEOM_WALK4) prim += ((size_t)p.nnodes4 * W4_FLOATS * 4 + 127) & ~(size_t)127;
     if (cfg.geom == GEOM_BVH || cfg.geom == GEOM_WALK_PAIR) prim += (size_t)p.nnodes * sizeof(BvhNode);
-    if (cfg.geom == GEOM_PAIR) prim += (size_t)p.nG * 32 * (cfg.nee ? 2 : 1);
+    if (cfg.geom == GEOM_PAIR) prim += (size_t)p.nG * PAIR_BOX_BYTES * (cfg.nee ? 2 : 1);
     size_t mats = (size_t)((p.nM * M_PLANES + 3) & ~3) * sizeof(float);
     size_t scan = (size_t)((2 * (cfg.workgroup / 64) + 2 + 3) & ~3) * sizeof(uint32_t);
     static const size_t extra = getenv("PT_EXTRA_LDS") ? (size_t)atol(getenv("PT_EXTRA_LDS")) : 0;   // occupancy experiments
