@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--settle-ms", type=float, default=120.0,
                     help="after the W warm-up steps keep rendering untimed iterations until the GPU has been busy this long "
                          "(DVFS: a 1 ms warm-up leaves the clock ~16 %% low for the whole of a 4 ms timed region); 0 = off")
+    ap.add_argument("--settle-max-ms", type=float, default=1500.0,
+                    help="upper bound of the settle phase (it ends earlier once the untimed chunks stop getting faster)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = ~1920x1080 pixels per rank of a frame that grows with N; strong = the config's frame cut into N tiles")
     ap.add_argument("--scene", default=None)
@@ -271,11 +273,22 @@ def main():
     # clock settle (untimed, reported): the W warm-up steps last W x ~0.2 ms here, and the GPU needs ~50-100 ms of load
     # to reach the clock it then holds.  The same frame keeps being rendered until the device has been busy for
     # settle_ms; the timed region is untouched: exactly K steps, bracketed as before.
+    # The phase lasts AT LEAST settle_ms and then goes on while the chunks are still getting faster -- a box that sat idle through a
+    # CPU-only phase (the oracle leg of a previous bench.py, a cold start) can take several hundred ms to reach its clock --, at most
+    # settle_max_ms: it ends when two chunks in a row are no more than 2 % faster than the one before them.
     settle_iters = 0
     chunk = 64
-    while args.settle_ms > 0 and (time.perf_counter() - t_w) * 1e3 < args.settle_ms and settle_iters < 65536:
+    chunk_s = []
+    while args.settle_ms > 0 and settle_iters < 65536:
+        elapsed_ms = (time.perf_counter() - t_w) * 1e3
+        if elapsed_ms >= args.settle_max_ms:
+            break
+        if elapsed_ms >= args.settle_ms and len(chunk_s) >= 3 and chunk_s[-1] > 0.98 * chunk_s[-2] and chunk_s[-2] > 0.98 * chunk_s[-3]:
+            break
+        t_c = time.perf_counter()
         r.render(next_iter + settle_iters, chunk)
         r.synchronize()
+        chunk_s.append(time.perf_counter() - t_c)
         settle_iters += chunk
     if world > 1:
         # every rank leaves the settle phase at its own iteration count (it only has to be warm); agree on the largest so
@@ -421,7 +434,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "warmup_settle": {"extra_untimed_iterations": settle_iters + (args.steps if value_cold is not None else 0),
-                              "settle_ms": args.settle_ms,
+                              "settle_ms": args.settle_ms, "settle_max_ms": args.settle_max_ms,
+                              "last_chunks_ms": [round(x * 1e3, 3) for x in chunk_s[-4:]],
                               "why": "GPU clock ramp (DVFS); the timed region is exactly `steps` iterations; value_cold = the same "
                                      "K steps right behind the W warm-up steps"},
             "value_cold": value_cold,

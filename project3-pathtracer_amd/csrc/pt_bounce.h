@@ -544,6 +544,9 @@ static constexpr uint32_t PAIR_QUEUE_BYTES = 2 * QCAP * 4 + 64 * 8 + 2 * 64 * 16
 #ifndef PT_PRETEST_OCT
 #define PT_PRETEST_OCT 1
 #endif
+#ifndef PT_PRETEST_B128
+#define PT_PRETEST_B128 1
+#endif
 static constexpr int PAIR_BOX_BYTES = PT_PRETEST_OCT ? 256 : 32;
 static constexpr uint32_t PAIR_QUEUE_MOTION_BYTES = PAIR_QUEUE_BYTES + 64 * 8;      // + the owners' shutter times
 static_assert(PAIR_QUEUE_BYTES <= WAVE_QUEUE_BYTES, "the pair queue lives in the hit queue's LDS region");
@@ -667,8 +670,14 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
         // in the plane, so for 1/d > 0 the lo plane IS the smaller product.  The eight 32-byte entries of a primitive cover all 64
         // banks once: lanes of different octants never meet on a bank.
         const float4 n4 = s_boxes[16 * g + octoff], f4 = s_boxes[16 * g + octoff + 1];
+#if PT_PRETEST_B128
+        // (the near entry's w holds the 0 of "not behind the origin": the read is then a full 16-byte one)
+        const float tn = fmaxf(fmaxf(__builtin_fmaf(n4.x, dinv.x, oinv.x), __builtin_fmaf(n4.y, dinv.y, oinv.y)),
+                               fmaxf(__builtin_fmaf(n4.z, dinv.z, oinv.z), n4.w));
+#else
         const float tn = fmaxf(fmaxf(__builtin_fmaf(n4.x, dinv.x, oinv.x), __builtin_fmaf(n4.y, dinv.y, oinv.y)),
                                fmaxf(__builtin_fmaf(n4.z, dinv.z, oinv.z), 0.0f));
+#endif
         const float tf = fminf(fminf(__builtin_fmaf(f4.x, dinv.x, oinv.x), __builtin_fmaf(f4.y, dinv.y, oinv.y)),
                                __builtin_fmaf(f4.z, dinv.z, oinv.z));
 #else
