@@ -133,8 +133,10 @@ typedef struct pt_options {
     int resident;         /* the later bounces of a batch as ONE launch with the paths resident in registers (a wave keeps the
                              paths that go on, refills the lanes of those that ended from the camera launch's ray pool): 1 = on
                              where a kernel exists for the launch shape (pair queue and batched walks, i.e. geom_path 0 / 5 / 7 / 8,
-                             without direct_light / scatter / motion_per_ray, depth >= 3), -1 = off (one launch per bounce),
-                             0 = library choice (default: on from depth 5 on, where it pays).  The image does not depend on it */
+                             without motion_per_ray, depth >= 3), -1 = off (one launch per bounce), 0 = library choice (default: on
+                             from depth 5 on for the plain estimator, where it pays; with direct_light / scatter the instances exist
+                             but measure - 3 ... + 1 %, so those stay on one launch per bounce unless asked).  The image does not
+                             depend on it */
 } pt_options;
 
 /* Device memory of a context, per launch sequence in flight: two ray pools of 40 B per ray slot (batch x tile pixels slots + up

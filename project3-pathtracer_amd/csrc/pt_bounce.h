@@ -1242,12 +1242,12 @@ enum { FEAT_NEE = 1, FEAT_MEDIA = 2, FEAT_MOTION = 4, FEAT_RESIDENT = 8 };
 template <int WG, bool FIRST, int GEOM, int COMPACT, int FEAT = 0>
 // (the resident-path instances of the batched walks are held to 80 VGPRs -- 6 waves per SIMD, three 512-thread workgroups per CU,
 // what the launch-per-bounce kernels reach unasked)
-__global__ __launch_bounds__(WG, ((FEAT & FEAT_RESIDENT) != 0 && (GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G)) ? 6
+__global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G)) ? 6
                                  : ((WG <= 256 && (FEAT & ~FEAT_RESIDENT) == 0) ? 5 : 1)) void k_bounce(const KParams p, const int bounce)
 {
     constexpr bool NEE = (FEAT & FEAT_NEE) != 0, MEDIA = (FEAT & FEAT_MEDIA) != 0, MOTION = (FEAT & FEAT_MOTION) != 0;
     constexpr bool RESIDENT = (FEAT & FEAT_RESIDENT) != 0;
-    static_assert(!RESIDENT || (!FIRST && COMPACT == 1 && !NEE), "resident paths: later bounces, compaction 1, no light sampling");
+    static_assert(!RESIDENT || (!FIRST && COMPACT == 1 && !MOTION), "resident paths: later bounces, compaction 1, no per-ray shutter time");
     constexpr int NW = WG / 64;
     constexpr bool PRIMS_IN_LDS = (GEOM == GEOM_LDS || GEOM == GEOM_QUEUE || GEOM == GEOM_PAIR);   // GEOM_BVH gathers records from global memory (L1/L2)
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
@@ -2052,9 +2052,14 @@ static const void *bounce_fn_feat(bool first)
 template <int WG, int GEOM>
 static const void *bounce_fn_geom(bool first, int compact, int feat)
 {
-    if ((feat & FEAT_RESIDENT) != 0) {        // resident paths: the pair queue and the batched walks, plain kernels, workgroups of 256 / 512
+    if ((feat & FEAT_RESIDENT) != 0) {        // resident paths: the pair queue and the batched walks, workgroups of 256 / 512; plain,
+                                              // with direct lighting and / or scattering (not with a shutter time per ray)
         if constexpr ((GEOM == GEOM_PAIR || GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) && (WG == 256 || WG == 512)) {
-            if (feat == FEAT_RESIDENT && compact == 1 && !first) return (const void *)k_bounce<WG, false, GEOM, 1, FEAT_RESIDENT>;
+            if (compact != 1 || first) return nullptr;
+            if (feat == FEAT_RESIDENT) return (const void *)k_bounce<WG, false, GEOM, 1, FEAT_RESIDENT>;
+            if (feat == (FEAT_RESIDENT | FEAT_NEE)) return (const void *)k_bounce<WG, false, GEOM, 1, FEAT_RESIDENT | FEAT_NEE>;
+            if (feat == (FEAT_RESIDENT | FEAT_MEDIA)) return (const void *)k_bounce<WG, false, GEOM, 1, FEAT_RESIDENT | FEAT_MEDIA>;
+            if (feat == (FEAT_RESIDENT | FEAT_NEE | FEAT_MEDIA)) return (const void *)k_bounce<WG, false, GEOM, 1, FEAT_RESIDENT | FEAT_NEE | FEAT_MEDIA>;
         }
         return nullptr;
     }

@@ -910,8 +910,10 @@ int configure(pt_ctx *c)
         // Library choice: from 5 bounces on.  The one launch saves depth - 2 launches and their tails and pays with a drain (the last
         // paths of every wave run up to depth - 1 trips alone): 1920x1080: - 5 % / +- 0 / + 4 % / + 4 % at depth 3 / 4 / 5 / 6;
         // 400x400: - 13 % / - 4 % / + 1 % / + 3 % (profiles/r04/ab_resident_paths.txt).  An explicit 1 takes it from 3 bounces on.
+        // With direct lighting or scattering the instances exist and are bit-exact, but do not pay (config 2 with direct lighting - 3.4 %,
+        // configs 3 / 5 +- 0 / + 1 %: the shadow-ray pass doubles a trip's work and halves the drain's weight): on request only.
         const int min_depth = (want == 0) ? 5 : 3;
-        if (want == 0) want = PT_RESIDENT_DEFAULT;
+        if (want == 0) want = (cfg.nee || cfg.media) ? -1 : PT_RESIDENT_DEFAULT;
         cfg.resident = 0;
         if (want > 0 && k.depth >= min_depth) {
             pt::LaunchCfg t = cfg;

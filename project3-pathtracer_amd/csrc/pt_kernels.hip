@@ -303,7 +303,7 @@ bool bounce_resident_available(const LaunchCfg &cfg)
 {
     LaunchCfg t = cfg;
     t.resident = 1;
-    return !cfg.nee && !cfg.media && !cfg.motion && cfg.compact == 1 && select_bounce(t, false) != nullptr;
+    return !cfg.motion && cfg.compact == 1 && select_bounce(t, false) != nullptr;
 }
 
 int bounce_max_blocks_per_cu(const KParams &p, const LaunchCfg &cfg)

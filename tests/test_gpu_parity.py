@@ -1413,13 +1413,39 @@ def test_resident_paths_refill_thresholds(pkg, refill, monkeypatch):
 
 
 def test_resident_paths_fall_back_where_no_kernel_exists(pkg):
-    """Direct lighting, scattering, the per-bounce geometry paths and depth < 3 keep one launch per bounce whatever the option
-    asks for: same image, launch count = depth."""
-    for opts, depth in (({"direct_light": 1}, 5), ({"geom_path": 1}, 5), ({"geom_path": 3}, 4), ({}, 2), ({}, 1)):
+    """The per-bounce geometry paths and depth < 3 keep one launch per bounce whatever the option asks for: same image,
+    launch count = depth."""
+    for opts, depth in (({"geom_path": 1}, 5), ({"geom_path": 3}, 4), ({}, 2), ({}, 1)):
         b, lb, sb = gpu_render(pkg, "sampleScene_spec.txt", 96, 54, depth, iters=3, batch=3, resident=1, **opts)
-        c, lc = cpu_render("sampleScene_spec.txt", 96, 54, depth, iters=3, **({"direct_light": 1} if "direct_light" in opts else {}))
+        c, lc = cpu_render("sampleScene_spec.txt", 96, 54, depth, iters=3)
         check(b, c, lb, lc, f"resident asked for with {opts}, depth {depth}")
         assert sb.bounce_launches == depth
+
+
+@pytest.mark.parametrize("scene,depth,opts", [
+    ("sampleScene_spec.txt", 6, {"direct_light": 1}),                                   # shadow-ray pass inside the resident loop
+    ("sampleScene_spec.txt", 8, {"direct_light": 1, "rr_start": 2, "batch": 3}),
+    ("sss_blobs.txt", 12, {"scatter": 1, "rotat": 1}),                                  # random walks inside media, paths resident
+    ("sss_blobs.txt", 10, {"scatter": 1, "direct_light": 1, "absorption": 1, "rr_start": 3, "rotat": 1}),
+    ("cloud256.txt", 9, {"direct_light": 1, "rotat": 1}),                               # batched walk + light sampling
+])
+def test_resident_paths_with_light_sampling_and_media(pkg, scene, depth, opts):
+    """The resident-path launch also exists with direct lighting (the chunk's second pass through the nearest-hit machinery for the
+    shadow rays runs inside the wave's loop; radiance entries accumulate along the path) and with scattering media: image,
+    live-ray and shadow-ray counts are the oracle's and the launch-per-bounce path's; two bounce launches per batch."""
+    o = dict(opts)
+    rotat = o.pop("rotat", 0)
+    w, h, iters = 112, 63, 5
+    a, la, sa = gpu_render(pkg, scene, w, h, depth, iters=iters, rotat=rotat, resident=-1, **o)
+    b, lb, sb = gpu_render(pkg, scene, w, h, depth, iters=iters, rotat=rotat, resident=1, **o)
+    sh = []
+    ok = {k: v for k, v in o.items() if k in ("direct_light", "scatter", "absorption", "rr_start")}
+    c, lc = cpu_render(scene, w, h, depth, iters=iters, rotat=rotat, shadow_out=sh, **ok)
+    check(b, c, lb, lc, f"resident paths with {opts} on {scene}")
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and la == lb
+    assert int(sb.shadow_rays) == int(sa.shadow_rays) == sh[0]
+    nb = -(-iters // (o.get("batch", 0) or 16))
+    assert sb.bounce_launches == 2 * nb and sa.bounce_launches == depth * nb
 
 
 def test_resident_paths_on_strip_tiles_and_resume(pkg):
