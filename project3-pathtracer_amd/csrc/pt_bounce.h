@@ -540,14 +540,8 @@ struct PairQueue {
     unsigned long long *dbg;
 };
 static constexpr uint32_t PAIR_QUEUE_BYTES = 2 * QCAP * 4 + 64 * 8 + 2 * 64 * 16 + 64 * 8;
-// LDS bytes per primitive of the pre-test's box table: eight (near, far) entries, one per direction octant (-DPT_PRETEST_OCT=0: lo, hi)
-#ifndef PT_PRETEST_OCT
-#define PT_PRETEST_OCT 1
-#endif
-#ifndef PT_PRETEST_B128
-#define PT_PRETEST_B128 1
-#endif
-static constexpr int PAIR_BOX_BYTES = PT_PRETEST_OCT ? 256 : 32;
+// LDS bytes per primitive of the pre-test's box table: eight (near, far) entries, one per direction octant
+static constexpr int PAIR_BOX_BYTES = 256;
 static constexpr uint32_t PAIR_QUEUE_MOTION_BYTES = PAIR_QUEUE_BYTES + 64 * 8;      // + the owners' shutter times
 static_assert(PAIR_QUEUE_BYTES <= WAVE_QUEUE_BYTES, "the pair queue lives in the hit queue's LDS region");
 
@@ -649,10 +643,8 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
     // slab distances as fma(plane, 1/d, -o/d): one instruction per plane; against (plane - o)/d this moves a plane by
     // less than 1.2e-6 |o|, far inside the boxes' padding
     const f3 oinv = FIRST ? mk(0, 0, 0) : mk(-(o.x * dinv.x), -(o.y * dinv.y), -(o.z * dinv.z));
-#if PT_PRETEST_OCT
     // the ray's direction octant as an offset (in float4) into a primitive's eight (near, far) entries
     const uint32_t octoff = ((__float_as_uint(dinv.x) >> 31) | ((__float_as_uint(dinv.y) >> 31) << 1) | ((__float_as_uint(dinv.z) >> 31) << 2)) * 2u;
-#endif
     for (int g = 0; g < p.nG; ++g) {
         // camera rays: the host's table says which primitives the 64 pixels of this chunk can see at all (primmask, bit g;
         // all ones without a table).  The bounds-checking build runs the test anyway and reports a pair that passes.
@@ -664,31 +656,16 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
         if (type > 1u) continue;                             // MESH: never has geometry
         // padded world box of the primitive against this lane's ray (camera rays: box relative to the shared eye), through
         // an LDS broadcast read: VGPR operands keep the six fma at the full VALU rate (SGPR operands halve it)
-#if PT_PRETEST_OCT
-        // near and far planes picked by ADDRESS: the LDS table holds every box once per direction octant as (near.xyz, far.xyz), so
-        // the slab test needs no min / max per axis (6 VALU per primitive and trip less).  Same tn / tf bit for bit: fma is monotonic
-        // in the plane, so for 1/d > 0 the lo plane IS the smaller product.  The eight 32-byte entries of a primitive cover all 64
-        // banks once: lanes of different octants never meet on a bank.
+        // near and far planes picked by ADDRESS: the LDS table holds every box once per direction octant as (near.xyz, 0)(far.xyz, -), so
+        // the slab test needs no min / max per axis (6 VALU per primitive and trip less: + 5.7 % on config 2, profiles/r04/
+        // ab_pretest_octant_planes.txt).  Same tn / tf bit for bit as the min / max form: fma is monotonic in the plane, so for 1/d > 0 the
+        // lo plane IS the smaller product.  The eight 32-byte entries of a primitive cover all 64 banks once.  (The near entry's w
+        // holds the 0 of "not behind the origin", which makes the read a full 16-byte one: + 0.6 %.)
         const float4 n4 = s_boxes[16 * g + octoff], f4 = s_boxes[16 * g + octoff + 1];
-#if PT_PRETEST_B128
-        // (the near entry's w holds the 0 of "not behind the origin": the read is then a full 16-byte one)
         const float tn = fmaxf(fmaxf(__builtin_fmaf(n4.x, dinv.x, oinv.x), __builtin_fmaf(n4.y, dinv.y, oinv.y)),
                                fmaxf(__builtin_fmaf(n4.z, dinv.z, oinv.z), n4.w));
-#else
-        const float tn = fmaxf(fmaxf(__builtin_fmaf(n4.x, dinv.x, oinv.x), __builtin_fmaf(n4.y, dinv.y, oinv.y)),
-                               fmaxf(__builtin_fmaf(n4.z, dinv.z, oinv.z), 0.0f));
-#endif
         const float tf = fminf(fminf(__builtin_fmaf(f4.x, dinv.x, oinv.x), __builtin_fmaf(f4.y, dinv.y, oinv.y)),
                                __builtin_fmaf(f4.z, dinv.z, oinv.z));
-#else
-        const float4 lo4 = s_boxes[2 * g], hi4 = s_boxes[2 * g + 1];
-        const f3 lo = mk(lo4.x, lo4.y, lo4.z), hi = mk(hi4.x, hi4.y, hi4.z);
-        const float x0 = __builtin_fmaf(lo.x, dinv.x, oinv.x), x1 = __builtin_fmaf(hi.x, dinv.x, oinv.x);
-        const float y0 = __builtin_fmaf(lo.y, dinv.y, oinv.y), y1 = __builtin_fmaf(hi.y, dinv.y, oinv.y);
-        const float z0 = __builtin_fmaf(lo.z, dinv.z, oinv.z), z1 = __builtin_fmaf(hi.z, dinv.z, oinv.z);
-        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
-        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-#endif
         // the compare's lane mask straight from v_cmp, and back into a predicate without VALU work
         const uint64_t mask = __builtin_amdgcn_fcmpf(tn, tf, FCMP_OLE) & vmask;
         if (mask == 0ull) continue;
@@ -1295,8 +1272,7 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
         // (FEAT_MOTION: box_world holds the boxes swept over the shutter interval, and camera rays have no common eye)
         const uint4 *src = reinterpret_cast<const uint4 *>((FIRST && !MOTION && !(p.lens_radius > 0.0f)) ? p.box_eye : p.box_world);
         uint4 *dst = reinterpret_cast<uint4 *>(smem + prim_bytes);
-#if PT_PRETEST_OCT
-        // per primitive eight entries (near.xyz, far.xyz), one per direction octant (bit 0 / 1 / 2 = the ray runs towards -x / -y / -z)
+        // per primitive eight entries (near.xyz, 0)(far.xyz, -), one per direction octant (bit 0 / 1 / 2 = the ray runs towards -x / -y / -z)
         auto stage_oct = [&](const uint4 *from, uint4 *to) {
             for (int k = tid; k < p.nG * 8; k += WG) {
                 const uint4 lo = from[2 * (k >> 3)], hi = from[2 * (k >> 3) + 1];
@@ -1307,13 +1283,6 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
         };
         stage_oct(src, dst);
         if (NEE) stage_oct(reinterpret_cast<const uint4 *>(p.box_world), dst + p.nG * 16);      // shadow rays start anywhere: world boxes, second half
-#else
-        for (int k = tid; k < p.nG * 2; k += WG) dst[k] = src[k];
-        if (NEE) {                                           // shadow rays start anywhere: world boxes, second half
-            const uint4 *srcw = reinterpret_cast<const uint4 *>(p.box_world);
-            for (int k = tid; k < p.nG * 2; k += WG) dst[p.nG * 2 + k] = srcw[k];
-        }
-#endif
     }
     if (GEOM == GEOM_BVH || GEOM == GEOM_WALK_PAIR) {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.bvh);
