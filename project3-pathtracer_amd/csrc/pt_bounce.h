@@ -98,6 +98,7 @@ struct Hit {
     uint32_t prim;      // index of the primitive hit (used by shadow rays)
     float t;            // world-space distance to the hit
     bool any;
+    uint32_t self_ok;   // resident paths: may the next bounce skip the primitive hit?  (Prim::self_r2, and for a sphere the hit point checked against it)
     unsigned long long dbg0, dbg1;   // DEBUG_PHASE2 builds: shader clocks of the pre-test loop / the last batches (else unused)
     unsigned long long dbg2, dbg3;   //   ... of the full batches inside the loop; lane-clocks of the last batches (clocks x busy lanes)
 };
@@ -627,9 +628,15 @@ __device__ __forceinline__ void pairBatch(const KParams &p, const PR *s_prims, c
 
 // Must be entered by all 64 lanes of the wave (lanes without a ray pass valid = false).
 // MOTION: s_boxes holds the primitives' boxes swept over the shutter interval (host), mymt = the calling lane's shutter time.
-template <bool FIRST, class PR, bool MOTION = false>
+// SKIP (resident paths): `skip` = the primitive this lane's ray just left on its OUTSIDE (0xFFFFFFFF: none).  A ray that starts
+// 0.0002 outside a convex primitive and moves away from it cannot meet it again -- the exact test of that pair always misses (for the
+// primitives the host marks: Prim::self_r2, pt_context.hip) -- but its origin lies inside the primitive's padded box, so the pre-test
+// would queue the pair every time: on the bundled scene, whose walls are tilted (ROTAT in radians) and fill the room with their
+// boxes, HALF of all pairs were such self pairs.  The bounds-checking build runs the exact test on every skipped pair and reports a hit.
+template <bool FIRST, class PR, bool MOTION = false, bool SKIP = false>
 __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_prims, const float4 *s_boxes, const PairQueue q,
-                                               f3 o, f3 d, bool valid, uint32_t lane, uint32_t primmask, MotionTime mymt = MotionTime())
+                                               f3 o, f3 d, bool valid, uint32_t lane, uint32_t primmask, MotionTime mymt = MotionTime(),
+                                               uint32_t skip = 0xFFFFFFFFu)
 {
     const unsigned long long ph_in = LANE_BUDGET<FIRST>() ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long fb_clk = 0ull, lb_lane_clk = 0ull;      // DEBUG_PHASE2: clocks inside full batches; lane-clocks of the last batches
@@ -667,7 +674,17 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
         const float tf = fminf(fminf(__builtin_fmaf(f4.x, dinv.x, oinv.x), __builtin_fmaf(f4.y, dinv.y, oinv.y)),
                                __builtin_fmaf(f4.z, dinv.z, oinv.z));
         // the compare's lane mask straight from v_cmp, and back into a predicate without VALU work
-        const uint64_t mask = __builtin_amdgcn_fcmpf(tn, tf, FCMP_OLE) & vmask;
+        uint64_t mask = __builtin_amdgcn_fcmpf(tn, tf, FCMP_OLE) & vmask;
+        if (SKIP) {
+            const uint64_t own = __builtin_amdgcn_uicmp(skip, (uint32_t)g, 32 /* ICMP_EQ */);      // lanes whose ray just left primitive g
+            if (DEBUG_BOUNDS && (mask & own) != 0ull) {
+                // (bounds-checking build: the skipped pair's exact test, in place; a hit is reported)
+                f3 ip, in;
+                const float ts = __builtin_amdgcn_inverse_ballot_w64(mask & own) ? intersectPrim<false>(s_prims[g], o, d, o, ip, in) : -1.0f;
+                if (ts > 0.0f) dbgInRange(p, 40, (unsigned long long)g + 1000ull, 0ull);
+            }
+            mask &= ~own;
+        }
         if (mask == 0ull) continue;
         if (DEBUG_BOUNDS && culled) { dbgInRange(p, 30, (unsigned long long)g + 1000ull, 0ull); continue; }
         const bool pass = __builtin_amdgcn_inverse_ballot_w64(mask);
@@ -721,6 +738,7 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
     h.any = false;
     h.material = 0;
     h.prim = 0;
+    h.self_ok = 0u;
     h.t = 0.0f;
     h.p = mk(0, 0, 0);
     h.n = mk(0, 0, 0);
@@ -736,6 +754,7 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
         h.t = __uint_as_float((uint32_t)(k >> 32));
         h.p = mk(b.x, b.y, b.z);
         h.material = P.material;
+        h.self_ok = P.self_r2 > 0.0f ? 1u : 0u;
         if (MOTION) {
             // the winner's transform at this lane's time: sphere centre = its translation column, box normal from its rows
             float minv[12], mfwd[12];
@@ -744,6 +763,9 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
         } else if (P.type == 0u) {
             const float4 c = *reinterpret_cast<const float4 *>(&P.cx);
             h.n = sphereNormal(h.p, mk(c.x, c.y, c.z));
+            // (the normal's own squared length: is the reported point where a hit from outside belongs -- see Prim::self_r2)
+            const f3 v = h.p - mk(c.x, c.y, c.z);
+            h.self_ok = (P.self_r2 > 0.0f && dot(v, v) > P.self_r2) ? 1u : 0u;
         } else {
             const float4 fn = reinterpret_cast<const float4 *>(s_prims + p.nG)[prim * faceStride<PR>() + face];   // face-normal table behind the records
             h.n = mk(fn.x, fn.y, fn.z);
@@ -961,9 +983,11 @@ __device__ __forceinline__ void pushTriangles(const KParams &p, const Prim *prim
 }
 
 // Must be entered by all 64 lanes of the wave.  prims: global records (gathered per lane through L1/L2).
-template <bool FIRST>
+// SKIP (resident paths): `skip` = the primitive this lane's ray just left on its outside (see nearestHitPairs); a popped leaf entry
+// asks its OWNER's skip through ds_bpermute.
+template <bool FIRST, bool SKIP = false>
 __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *prims, const Walk4 w, const PairQueue q,
-                                               f3 o, f3 d, bool valid, uint32_t lane, uint32_t span)
+                                               f3 o, f3 d, bool valid, uint32_t lane, uint32_t span, uint32_t skip = 0xFFFFFFFFu)
 {
     q.key[lane] = KEY_NONE;                                  // (q.po / q.pd: the ray stays in this lane's registers)
     uint32_t head[2] = {0u, 0u}, tail[2] = {0u, 0u};        // wave-uniform
@@ -999,7 +1023,14 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
         const float z0 = __builtin_fmaf(__uint_as_float(bq[2]), dinv.z, oinv.z), z1 = __builtin_fmaf(__uint_as_float(bq[6]), dinv.z, oinv.z);
         const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
         const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-        const bool pass = valid && tn <= tf;
+        bool pass = valid && tn <= tf;
+        if (SKIP) {
+            if (DEBUG_BOUNDS && pass && skip == (uint32_t)g) {      // (bounds-checking build: the skipped pair's exact test; a hit is reported)
+                f3 ip, in;
+                if (intersectPrim<false>(prims[g], o, d, o, ip, in) > 0.0f) dbgInRange(p, 41, (unsigned long long)g + 1000ull, 0ull);
+            }
+            pass = pass && skip != (uint32_t)g;
+        }
         if (type == 3u) pushTriangles<FIRST>(p, prims, q, thead, ttail, pass, (uint32_t)g, lane, lane);
         else pushPairs<FIRST>(p, prims, q, head, tail, pass && type == 0u, pass && type == 1u, (uint32_t)g, lane, lane);
     }
@@ -1044,9 +1075,23 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
         if (leafm != 0ull) {
             // child words: 100x.. sphere, 110x.. cube, 101x.. triangle leaf
             const uint32_t cls = e >> 29;
-            const bool sph = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_uicmp(cls, 4u, 32 /* ICMP_EQ */));
-            const bool cube = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_uicmp(cls, 6u, 32));
+            bool sph = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_uicmp(cls, 4u, 32 /* ICMP_EQ */));
+            bool cube = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_uicmp(cls, 6u, 32));
             const bool tri = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_uicmp(cls, 5u, 32));
+            if (SKIP) {
+                // the leaf of the primitive the owner's ray just left: no pair (every lane of the wave is here: uniform control flow)
+                const uint32_t oskip = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)skip);
+                const bool own = leaf && index == oskip;
+                if (DEBUG_BOUNDS && __ballot(own) != 0ull) {
+                    // (bounds-checking build: the skipped pair's exact test on the owner's ray; a hit is reported)
+                    auto fo = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(owner << 2), __float_as_int(v))); };
+                    const f3 oo = mk(fo(o.x), fo(o.y), fo(o.z)), od = mk(fo(d.x), fo(d.y), fo(d.z));
+                    f3 ip, in;
+                    if (own && intersectPrim<false>(prims[index], oo, od, oo, ip, in) > 0.0f) dbgInRange(p, 42, (unsigned long long)index + 1000ull, 0ull);
+                }
+                sph = sph && !own;
+                cube = cube && !own;
+            }
             if (DEBUG_BOUNDS && listed) {                     // the list already queued the pairs: only check it
                 bool on_list = !leaf;
                 for (uint32_t j = 0; j < list_n; ++j) on_list = on_list || lst[j] == index;
@@ -1128,7 +1173,12 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
         h.t = __uint_as_float((uint32_t)(k >> 32));
         h.p = mk(b.x, b.y, b.z);
         h.material = P.material;
-        if (P.type == 0u) h.n = sphereNormal(h.p, mk(P.cx, P.cy, P.cz));
+        h.self_ok = P.self_r2 > 0.0f ? 1u : 0u;
+        if (P.type == 0u) {
+            h.n = sphereNormal(h.p, mk(P.cx, P.cy, P.cz));
+            const f3 v = h.p - mk(P.cx, P.cy, P.cz);             // (see Prim::self_r2)
+            h.self_ok = (P.self_r2 > 0.0f && dot(v, v) > P.self_r2) ? 1u : 0u;
+        }
         else if (P.type == 3u) h.n = mk(P.fwd[0], P.fwd[1], P.fwd[2]);
         else {
             const float4 fn = reinterpret_cast<const float4 *>(p.face_n)[prim * 8u + face];
@@ -1140,9 +1190,10 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
 
 // nearest hit of (o, d) for the lanes with want == true, by the GEOM path.  Every lane of the wave must make the call
 // (the hit queue uses all 64 lanes as workers whatever their own ray).
-template <int GEOM, bool FIRST, bool MOTION = false>
+template <int GEOM, bool FIRST, bool MOTION = false, bool SKIP = false>
 __device__ __forceinline__ Hit nearestHit(const KParams &p, const PrimPad *s_prims, const float4 *s_nodes, const WaveQueue &wq,
-                                          f3 o, f3 d, bool want, uint32_t lane, uint32_t primmask = 0xFFFFFFFFu, MotionTime mt = MotionTime())
+                                          f3 o, f3 d, bool want, uint32_t lane, uint32_t primmask = 0xFFFFFFFFu, MotionTime mt = MotionTime(),
+                                          uint32_t skip = 0xFFFFFFFFu)
 {
     if (GEOM == GEOM_QUEUE) return nearestHitQueued<FIRST>(p, s_prims, wq, o, d, want, lane);
     if (GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR || GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) {
@@ -1166,15 +1217,16 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const PrimPad *s_pri
             pq.dir = nullptr;
             pq.po = o;
             pq.pd = d;
-            return nearestHitWalk4<FIRST>(p, p.prims, w4, pq, o, d, want, lane, (FIRST && p.span_off != nullptr) ? primmask : 0xFFFFFFFFu);
+            return nearestHitWalk4<FIRST, SKIP>(p, p.prims, w4, pq, o, d, want, lane, (FIRST && p.span_off != nullptr) ? primmask : 0xFFFFFFFFu, skip);
         }
         if (GEOM == GEOM_WALK_PAIR) return nearestHitWalkPairs<FIRST>(p, p.prims, s_nodes, pq, o, d, want, lane);
-        return nearestHitPairs<FIRST, PrimPad, MOTION>(p, s_prims, s_nodes, pq, o, d, want, lane, primmask, mt);
+        return nearestHitPairs<FIRST, PrimPad, MOTION, SKIP>(p, s_prims, s_nodes, pq, o, d, want, lane, primmask, mt, skip);
     }
     Hit h;
     h.any = false;
     h.material = 0;
     h.prim = 0;
+    h.self_ok = 0u;
     h.t = 0.0f;
     h.p = mk(0, 0, 0);
     h.n = mk(0, 0, 0);
@@ -1441,7 +1493,8 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
     bool valid = false;
     f3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(1, 1, 1);
     uint32_t pix = 0;
-    uint32_t lb = (uint32_t)bounce;                  // the bounce this lane's path is at (RESIDENT: per lane)
+    uint32_t lb = (uint32_t)bounce;                  // RESIDENT, per lane: the bounce the lane's path is at (bits 0..7) | (1 + the primitive its
+                                                     // ray just left on the outside and cannot meet again) << 8  (0: none)
     for (uint32_t R = blockIdx.x; RESIDENT || R * NW < total_chunks; R += RESIDENT ? 0u : gridDim.x, ++round) {     // (dealt chunks: workgroup-uniform trip count)
         const uint32_t my_chunk = R * NW + wave;                  // dealt: round-robin over the workgroups' waves
         const unsigned long long tc0 = (DEBUG_PHASE || PT_DEBUG_PHASE == 2 || PT_DEBUG_PHASE == 3) ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -1487,7 +1540,8 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
             pix = 0;
         }
         const uint32_t chunk_first_ray = my_chunk * 64u;          // (bounce 0: rays are numbered slot by slot, pixel by pixel)
-        const bool lastb = RESIDENT ? (lb == (uint32_t)(p.depth - 1)) : last;      // (RESIDENT: per lane)
+        const uint32_t cb = RESIDENT ? (lb & 0xFFu) : (uint32_t)bounce;            // this trip's bounce (RESIDENT: per lane)
+        const bool lastb = RESIDENT ? (cb == (uint32_t)(p.depth - 1)) : last;
         MotionTime mt;
         mt.k = 0u;
         mt.f = 0.0f;
@@ -1586,6 +1640,7 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
         if (COMPACT == 0) live_count += (uint32_t)__popcll(__ballot(valid));
 
         bool alive = false;
+        bool leaves_outside = false;      // RESIDENT: the new ray starts on the OUTSIDE of the primitive it was shaded on, moving away from it
         const unsigned long long c1 = (DEBUG_PHASE || PT_DEBUG_PHASE == 2 || PT_DEBUG_PHASE == 3) ? __builtin_amdgcn_s_memtime() : 0ull;
         // camera rays share the eye (host-side eye transforms and eye-relative boxes) unless a lens spreads their origins
         // camera rays of the pair path: which primitives the chunk's 64 pixels can see (host-built table, one word per span
@@ -1616,8 +1671,9 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
             h.any = false; h.material = 0; h.prim = 0; h.t = 0.0f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0);
             if (valid) h = nearestHitMotion(p, o, d, mt);
         } else {
-            h = (FIRST && p.lens_radius > 0.0f) ? nearestHit<GEOM, false>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane)
-                                                : nearestHit<GEOM, FIRST>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane, primmask);
+            if (RESIDENT) h = nearestHit<GEOM, false, false, true>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane, 0xFFFFFFFFu, MotionTime(), (lb >> 8) - 1u);
+            else h = (FIRST && p.lens_radius > 0.0f) ? nearestHit<GEOM, false>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane)
+                                                     : nearestHit<GEOM, FIRST>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane, primmask);
         }
         const unsigned long long c2 = (DEBUG_PHASE || PT_DEBUG_PHASE == 2 || PT_DEBUG_PHASE == 3) ? __builtin_amdgcn_s_memtime() : 0ull;
         if (LANE_BUDGET<FIRST>()) { lb_nvalid = (uint32_t)__popcll(__ballot(valid)); lb_nhit = (uint32_t)__popcll(__ballot(valid && h.any)); }
@@ -1647,7 +1703,7 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
                     // calculateBSDF: pick the lobe, build the next ray
                     did_bsdf = true;
                     const uint32_t slot = NEE ? ((pix >> SLOT_SHIFT) & (uint32_t)(MAXSLOT - 1)) : (pix >> SLOT_SHIFT);
-                    const uint32_t kb = RESIDENT ? s_keys[lb * (uint32_t)MAXSLOT + slot] : s_key[slot];
+                    const uint32_t kb = RESIDENT ? s_keys[cb * (uint32_t)MAXSLOT + slot] : s_key[slot];
                     // the bounce's draws in stream order u_select, xi1, xi2, u_rr, then (light sampling) u_light, u_seed or
                     // (inside a medium) u_sd, u_s2, u_s3: each by its own jump from the seed, computed where it is used
                     const uint32_t s0 = minstd_seed(wang_hash(globalPixel(p, pix & PIX_MASK) ^ kb));
@@ -1742,7 +1798,7 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
                     f3 nd;
                     f3 bias_n = nf;
                     float bias = 0.0002f;                 // RAY_BIAS_AMOUNT, ref: src/utilities.h:26
-                    bool scattered = false, pass_through = false;
+                    bool scattered = false, pass_through = false, transmitted = false;
                     if (medium) {
                         if (backside) {
                             // the segment ran through the medium: three more draws of the bounce's stream decide whether
@@ -1801,6 +1857,7 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
                             // world units, more than the bias for objects scaled by > 2
                             nd = tdir;
                             bias_n = -nf;
+                            transmitted = true;
                             f3 v;
                             if (MOTION) {
                                 float minv[12], mfwd[12];
@@ -1825,7 +1882,11 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
                     if (!scattered) o = h.p + bias * bias_n;
                     d = nd;
                     alive = true;
-                    if (p.rr_start >= 0 && (RESIDENT ? (int)lb : bounce) >= p.rr_start) {      // Russian roulette
+                    // the new ray starts 0.0002 outside the primitive, in the hemisphere of its outward normal (diffuse, mirror or Fresnel
+                    // reflection off the OUTER side): the next bounce's search need not look at that primitive (where the host vouches
+                    // for it: Prim::self_r2)
+                    leaves_outside = RESIDENT && !scattered && !pass_through && !transmitted && !backside && h.self_ok != 0u;
+                    if (p.rr_start >= 0 && (int)cb >= p.rr_start) {      // Russian roulette
                         float q = T.x;
                         if (T.y > q) q = T.y;
                         if (T.z > q) q = T.z;
@@ -1892,9 +1953,9 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
         if (RESIDENT) {
             // a path that ended is counted at the bounce it ended at (the per-bounce live counts follow from the histogram);
             // one that goes on stays where it is, a bounce further
-            if (valid && !alive) atomicAdd(&s_term[lb], 1u);
+            if (valid && !alive) atomicAdd(&s_term[cb], 1u);
             valid = alive;
-            lb += 1u;
+            lb = (cb + 1u) | (leaves_outside ? ((h.prim + 1u) << 8) : 0u);
             if (DEBUG_PHASE2 && GEOM == GEOM_PAIR) { const unsigned long long c4 = __builtin_amdgcn_s_memtime() - c3; lbud[11] += c4; lbud[12] += c4 * (unsigned long long)__popcll(__ballot(alive)); }
             continue;
         }

@@ -179,16 +179,60 @@ float *image_ptr(pt_ctx *c) { return c->d_image_bound ? c->d_image_bound : c->d_
 // ---- culling hierarchy over the primitives (host build; the kernels only read it) -------------------------
 struct Aabb { float lo[3], hi[3]; };
 
+// What the REFERENCE'S sphere test hits is not the sphere.  Its radicand, b*b - (ro.ro - 0.25) with b = ro.rd, is formed from fp32
+// products of object-space coordinates (ref: src/intersections.h:81-117; the outer subtraction alone is in double): for a ray that
+// starts R object units away both terms are ~ R^2 and carry ~ 16 ulp-halves of it, so the test reports a hit whenever the ray passes
+// within sqrt(0.25 + E) of the centre, E <= 20 eps R^2 + 64 eps (s_max / s_min) R (the second term: rounding of the transformed
+// direction, seen from R away), eps = 2^-24 -- and its hit point lies within that radius too.  A sphere of radius 0.11 met from 15 world
+// units away is 1 % larger than it is; one of radius 0.01 across a room of 100 is hit by rays that pass several radii away.  The oracle
+// renders exactly that, so every culling bound of a sphere is taken around the INFLATED sphere: this returns sqrt(1 + 4 E) for rays
+// that start at most D world units from the centre (configure() bounds D by the scene).  Cubes: the slab distances err by a few ulps
+// of themselves, i.e. by ~ 1e-7 D in world units whatever the scale: an absolute pad.
+double sphere_noise_factor(const pt_static_geom &g, double D)
+{
+    if (!(D > 0.0)) return 1.0;
+    const float *r0 = &g.transform.x.x, *r1 = &g.transform.y.x, *r2 = &g.transform.z.x;
+    double len[3], col[3][3], F2 = 0.0;
+    for (int j = 0; j < 3; ++j) {
+        col[j][0] = r0[j]; col[j][1] = r1[j]; col[j][2] = r2[j];
+        len[j] = sqrt(col[j][0] * col[j][0] + col[j][1] * col[j][1] + col[j][2] * col[j][2]);
+        F2 += len[j] * len[j];
+    }
+    bool orthogonal = true;
+    for (int a = 0; a < 3; ++a)
+        for (int b = a + 1; b < 3; ++b)
+            if (fabs(col[a][0] * col[b][0] + col[a][1] * col[b][1] + col[a][2] * col[b][2]) > 1e-4 * len[a] * len[b]) orthogonal = false;
+    double smin, smax;
+    if (orthogonal) {
+        smin = std::min(len[0], std::min(len[1], len[2])) * (1.0 - 2e-4);
+        smax = std::max(len[0], std::max(len[1], len[2])) * (1.0 + 2e-4);
+    } else {                                  // singular values: s_max <= ||M||_F, s_min = |det| / (s_1 s_2) >= 2 |det| / ||M||_F^2
+        const double det = col[0][0] * (col[1][1] * col[2][2] - col[1][2] * col[2][1]) - col[1][0] * (col[0][1] * col[2][2] - col[0][2] * col[2][1]) +
+                           col[2][0] * (col[0][1] * col[1][2] - col[0][2] * col[1][1]);
+        smax = sqrt(F2);
+        smin = 2.0 * fabs(det) / F2;
+    }
+    const double eps = 5.9604644775390625e-8, FMAX = 1e6;
+    if (!(smin > 0.0) || !(smax > 0.0)) return FMAX;
+    const double R = D / smin + 0.5;
+    const double E = 20.0 * eps * R * R + 64.0 * eps * (smax / smin) * R;
+    const double f = sqrt(1.0 + 4.0 * E);
+    return f < FMAX ? f : FMAX;                 // (a NaN compares false: FMAX)
+}
+
 // Padded world-space box of one primitive: |x_a - c_a| <= 0.5 * sum_i |M[a][i]| for the unit cube and
 // <= 0.5 * sqrt(sum_i M[a][i]^2) for the r = .5 sphere (M = rows 0..2 of the transform); +1 % and +1e-3 absorb the
-// fp32 rounding of the traversal's slab test and the 1e-4 back-off of getPointOnRay.
-Aabb prim_bounds(const pt_static_geom &g, double rel = 1.01, double abs_pad = 1e-3)
+// fp32 rounding of the traversal's slab test and the 1e-4 back-off of getPointOnRay.  D: how far from the primitive's centre a ray
+// tested against it can start (0: not known yet) -- sphere_noise_factor above.
+Aabb prim_bounds(const pt_static_geom &g, double rel = 1.01, double abs_pad = 1e-3, double D = 0.0)
 {
     const float *rows[3] = {&g.transform.x.x, &g.transform.y.x, &g.transform.z.x};
     Aabb b;
+    const double noise = (g.type == PT_SPHERE) ? sphere_noise_factor(g, D) : 1.0;
+    abs_pad += 2e-6 * D;
     for (int a = 0; a < 3; ++a) {
         const double m0 = rows[a][0], m1 = rows[a][1], m2 = rows[a][2], c = rows[a][3];
-        double h = (g.type == PT_SPHERE) ? 0.5 * sqrt(m0 * m0 + m1 * m1 + m2 * m2) : 0.5 * (fabs(m0) + fabs(m1) + fabs(m2));
+        double h = (g.type == PT_SPHERE) ? 0.5 * sqrt(m0 * m0 + m1 * m1 + m2 * m2) * noise : 0.5 * (fabs(m0) + fabs(m1) + fabs(m2));
         h = h * rel + abs_pad + 1e-6 * fabs(c);
         b.lo[a] = (float)(c - h);
         b.hi[a] = (float)(c + h);
@@ -482,6 +526,57 @@ int configure(pt_ctx *c)
         }
         return b;
     };
+    // reach[i]: how far from the centre of geom i a ray that is tested against it can start -- the eye (the lens around it) or a point
+    // of (the padded bounds of) any primitive, at either end of a motion.  The bounds of spheres depend on it (sphere_noise_factor), so
+    // this is a fixed point: the inflation is ~ 1e-3 of the reach for ordinary shapes and the iteration settles at once; a scene where it
+    // does not (spheres squeezed by factors of hundreds) gets the largest reach the factor knows, and culls nothing of them.
+    std::vector<double> reach(nGeoms, 0.0);
+    {
+        bool settled = false;
+        for (int pass = 0; pass < 8 && !settled; ++pass) {
+            double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+            bool first = true;
+            auto grow = [&](const double *l, const double *h) {
+                for (int a = 0; a < 3; ++a) {
+                    if (first || l[a] < lo[a]) lo[a] = l[a];
+                    if (first || h[a] > hi[a]) hi[a] = h[a];
+                }
+                first = false;
+            };
+            auto grow_box = [&](const Aabb &b) {
+                const double l[3] = {b.lo[0], b.lo[1], b.lo[2]}, h[3] = {b.hi[0], b.hi[1], b.hi[2]};
+                grow(l, h);
+            };
+            auto grow_eye = [&](const pt_camera_data &cam) {
+                const double r = o.lens_radius > 0.0f ? (double)o.lens_radius * 1.001 : 0.0;
+                const double l[3] = {cam.position.x - r, cam.position.y - r, cam.position.z - r};
+                const double h[3] = {cam.position.x + r, cam.position.y + r, cam.position.z + r};
+                grow(l, h);
+            };
+            grow_eye(c->cam);
+            if (c->have_cam_next) grow_eye(c->cam_next);
+            for (size_t i = 0; i < nGeoms; ++i) {
+                if (c->geoms[i].type == PT_MESH) continue;
+                grow_box(prim_bounds(c->geoms[i], 1.01, 1e-3, reach[i]));
+                if (!c->geoms_next.empty()) grow_box(prim_bounds(c->geoms_next[i], 1.01, 1e-3, reach[i]));
+            }
+            for (size_t t = 0; t < nT; ++t) grow_box(tri_bounds(t, 1.01, 1e-3));
+            const double c0[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+            const double rs = 0.5 * sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+            settled = true;
+            for (size_t i = 0; i < nGeoms; ++i) {
+                auto dist = [&](const pt_static_geom &g) {
+                    const double dx = g.transform.x.w - c0[0], dy = g.transform.y.w - c0[1], dz = g.transform.z.w - c0[2];
+                    return sqrt(dx * dx + dy * dy + dz * dz);
+                };
+                double d = dist(c->geoms[i]);
+                if (!c->geoms_next.empty()) d = std::max(d, dist(c->geoms_next[i]));
+                d += rs;
+                if (!(d <= reach[i])) { settled = false; reach[i] = d * 1.002; }          // (a NaN never settles)
+            }
+        }
+        if (!settled) for (size_t i = 0; i < nGeoms; ++i) reach[i] = 1e9;
+    }
     k.nG = (int)nP;
     k.ntri = (int)nT;
     k.nM = (int)c->mats.size();
@@ -524,8 +619,46 @@ int configure(pt_ctx *c)
             double rad;
             if (orthogonal) rad = (g.type == PT_SPHERE) ? 0.5 * maxlen : 0.5 * sqrt(sumsq);   // r*s_max / half diagonal
             else rad = (g.type == PT_SPHERE) ? 0.5 * sqrt(sumsq) : 0.5 * sum;                  // Frobenius / triangle bound
-            rad = rad * 1.02 + 1e-3;
+            if (g.type == PT_SPHERE) rad *= sphere_noise_factor(g, reach[i]);                  // (what the reference's test hits)
+            rad = rad * 1.02 + 1e-3 + 2e-6 * reach[i];
             p.bound_r2 = (float)(rad * rad);
+            // self_r2: may a ray that leaves this primitive on its OUTSIDE skip it at its next bounce (resident paths)?  Mathematically a
+            // ray that starts outside a convex primitive and moves away from it cannot meet it again; the kernels may only rely on
+            // that where the REFERENCE'S ARITHMETIC agrees for every such ray (the oracle tests the primitive all the same):
+            //  (i)  the shading normal must be the surface normal -- a uniformly scaled sphere (the reference's sphere normal is the
+            //       direction from the centre, which an ellipsoid's is not: a ray sampled about it can dive back into an ellipsoid) or a
+            //       cube under a transform with orthogonal columns;
+            //  (ii) the new origin, hit point + 0.0002 * normal, must really lie outside.  A cube's slab distances are accurate to a few
+            //       ulps of the ray's length (error along the face axis ~ 3e-7 * distance in WORLD units, whatever the scale): with the
+            //       scene within 128 units that is <= 1e-4 of margin against the 2e-4 bias.  A SPHERE's quadratic is not: b*b - c cancels
+            //       for a ray that comes from far away relative to the sphere's size (fp32 error ~ (distance / scale)^2 * 6e-8 object
+            //       units), and the reported point can lie inside the sphere by more than the bias -- the path then bounces on inside
+            //       (cloud256: a sphere of radius 0.11 met from 12.5 units away; the oracle renders exactly that).  So for spheres the
+            //       kernels check the hit point itself: skipping needs |p - c| > r - 0.0002 + margin, i.e. an origin at least `margin`
+            //       outside, margin = 2e-5 + 1e-5 * scale + rounding of the check (coordinates up to `coord`);
+            //  (iii) moderate sizes: the object-space offset of the bias, 0.0002 / scale, must stay far above fp32 noise (scale <= 64).
+            // The bounds-checking build runs the exact test on every skipped pair and reports a hit.
+            {
+                bool tight = true;                        // orthogonality to 1e-6 (the 1e-4 above only sizes a culling sphere)
+                for (int a = 0; a < 3; ++a)
+                    for (int b = a + 1; b < 3; ++b) {
+                        const double dp = colv[a][0] * colv[b][0] + colv[a][1] * colv[b][1] + colv[a][2] * colv[b][2];
+                        if (fabs(dp) > 1e-6 * len[a] * len[b]) tight = false;
+                    }
+                double minlen = len[0];
+                for (int col = 1; col < 3; ++col) if (len[col] < minlen) minlen = len[col];
+                const bool uniform = maxlen - minlen <= 1e-6 * maxlen;
+                const double coord = sqrt((double)p.cx * p.cx + (double)p.cy * p.cy + (double)p.cz * p.cz) + rad;       // (largest coordinate of its surface)
+                const bool sane = maxlen <= 64.0 && minlen > 0.0 && coord <= 128.0;      // (a NaN fails every compare)
+                p.self_r2 = 0.0f;
+                if (tight && sane && g.type == PT_CUBE) p.self_r2 = 1.0f;
+                if (tight && sane && g.type == PT_SPHERE && uniform) {
+                    const double r = 0.5 * maxlen, margin = 2e-5 + 1e-5 * maxlen + 8.0 * coord * 6e-8;
+                    const double rc = r - 0.0002 + margin;
+                    if (margin < 1.5e-4 && rc > 0.0) p.self_r2 = (float)(rc * rc * (1.0 + 1e-6));
+                }
+                if (getenv("PT_NO_SELF_SKIP")) p.self_r2 = 0.0f;      // (ablation switch)
+            }
         }
         for (size_t t = 0; t < nT; ++t) {
             ptd::Prim &p = prims[nGeoms + t];
@@ -688,7 +821,7 @@ int configure(pt_ctx *c)
         for (size_t i = 0; i < nP; ++i) {
             // hit-or-miss culling only (no distance pruning): the padding just has to cover fp32 rounding (1e-6 of the
             // coordinates), and a tight one keeps a ray that leaves a wall (0.0002 above it) outside that wall's box
-            const Aabb b = i < nGeoms ? prim_bounds(c->geoms[i], 1.005, 1e-4) : tri_bounds(i - nGeoms, 1.005, 1e-4);
+            const Aabb b = i < nGeoms ? prim_bounds(c->geoms[i], 1.005, 1e-4, reach[i]) : tri_bounds(i - nGeoms, 1.005, 1e-4);
             for (int a = 0; a < 3; ++a) { bw[8 * i + (size_t)a] = b.lo[a]; bw[8 * i + 4 + (size_t)a] = b.hi[a]; }
             const double e[3] = {c->cam.position.x, c->cam.position.y, c->cam.position.z};
             for (int a = 0; a < 3; ++a) {
@@ -751,7 +884,7 @@ int configure(pt_ctx *c)
                 memcpy(&kn[((size_t)j * nGeoms + i) * 12], &fwd, 12 * sizeof(float));
                 pt_static_geom gk = a;
                 gk.transform = fwd;
-                const Aabb bk = prim_bounds(gk, 1.005, 1e-4);
+                const Aabb bk = prim_bounds(gk, 1.005, 1e-4, reach[i]);
                 for (int ax = 0; ax < 3; ++ax) {
                     if (j == 0 || bk.lo[ax] < swept[8 * i + (size_t)ax]) swept[8 * i + (size_t)ax] = bk.lo[ax];
                     if (j == 0 || bk.hi[ax] > swept[8 * i + 4 + (size_t)ax]) swept[8 * i + 4 + (size_t)ax] = bk.hi[ax];
@@ -798,7 +931,7 @@ int configure(pt_ctx *c)
         float slo[3] = {0, 0, 0}, shi[3] = {0, 0, 0};
         bool first_box = true;
         for (size_t i = 0; i < nP; ++i) {
-            boxes[i] = i < nGeoms ? prim_bounds(c->geoms[i], 1.005, 1e-4) : tri_bounds(i - nGeoms, 1.005, 1e-4);    // hit-or-miss culling: the distance pruning has its own slack
+            boxes[i] = i < nGeoms ? prim_bounds(c->geoms[i], 1.005, 1e-4, reach[i]) : tri_bounds(i - nGeoms, 1.005, 1e-4);    // hit-or-miss culling: the distance pruning has its own slack
             if (ptype[i] == PT_MESH) continue;
             for (int a = 0; a < 3; ++a) {
                 if (first_box || boxes[i].lo[a] < slo[a]) slo[a] = boxes[i].lo[a];

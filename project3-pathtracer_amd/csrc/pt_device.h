@@ -123,7 +123,11 @@ struct Prim {
     uint32_t type;       // 0 sphere, 1 cube, 2 mesh (never hit: its triangles are records of their own), 3 triangle
     uint32_t material;
     float area;          // surface area when the primitive is a light (direct lighting), else 0
-    uint32_t pad1;
+    float self_r2;       // resident paths: may a ray that leaves this primitive on its outside skip it at its next bounce?  0: never.
+                         // Cube (orthogonal transform, moderate size and place): any value > 0.  Sphere (uniformly scaled): the hit point must
+                         // lie beyond this squared distance from the centre -- the reference's quadratic loses digits for rays that come
+                         // from far away relative to the sphere's size and can report a hit point INSIDE it by more than the 0.0002 bias;
+                         // the bounce then starts inside and the primitive IS met again (pt_context.hip)
     float inv[12];       // inverseTransform rows x,y,z (x y z w each)
     float fwd[12];       // transform rows x,y,z
     float cx, cy, cz;    // transform * (0,0,0,1), evaluated on the host with multiplyMV's operation order

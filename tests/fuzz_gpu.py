@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O  # noqa: E402
 from __graft_entry__ import load_package  # noqa: E402
-from test_gpu_parity import _random_scene  # noqa: E402
+from test_gpu_parity import _random_scene, _skip_stress_scene  # noqa: E402
 
 
 def main():
@@ -49,6 +49,12 @@ def main():
         rng4 = np.random.default_rng(770000 + case)
         gopts["resident"] = int(rng4.choice([-1, 1, 1]))
         os.environ["PT_REFILL_MIN"] = str(int(rng4.choice([1, 4, 16, 33, 64])))
+        if rng4.random() < 0.2:
+            # ... and scenes where the reference's sphere arithmetic loses its digits (spheres far smaller than the rays that reach them
+            # are long: the culling bounds have to hold what the test HITS, and a resident path may only skip the primitive it leaves
+            # where the test would miss it -- Prim::self_r2)
+            geoms, mats, eye, view, up, fovy = _skip_stress_scene(5000 + case)
+            n_prims = len(geoms)
         if rng.random() < 0.4:
             opts["direct_light"] = 1
         if rng.random() < 0.4:

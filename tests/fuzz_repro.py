@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O  # noqa: E402
 from __graft_entry__ import load_package  # noqa: E402
-from test_gpu_parity import _random_scene  # noqa: E402
+from test_gpu_parity import _random_scene, _skip_stress_scene  # noqa: E402
 
 pkg = load_package()
 
@@ -31,6 +31,12 @@ def run(case, override):
     iters = int(rng.integers(1, 5))
     opts = dict(rr_start=int(rng.integers(-1, depth)), seed=int(rng.integers(0, 1000)))
     gopts = dict(geom_path=int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8] if case % 3 == 0 else [0, 1, 2, 3, 4, 5, 6, 7])), batch=int(rng.choice([0, 1, 2, 3, 7, 16])))
+    rng4 = np.random.default_rng(770000 + case)               # (round 4's dimensions, as tests/fuzz_gpu.py draws them)
+    gopts["resident"] = int(rng4.choice([-1, 1, 1]))
+    os.environ.setdefault("PT_REFILL_MIN", str(int(rng4.choice([1, 4, 16, 33, 64]))))
+    if rng4.random() < 0.2:
+        geoms, mats, eye, view, up, fovy = _skip_stress_scene(5000 + case)
+        n_prims = len(geoms)
     if rng.random() < 0.4:
         opts["direct_light"] = 1
     if rng.random() < 0.4:

@@ -1422,6 +1422,67 @@ def test_resident_paths_fall_back_where_no_kernel_exists(pkg):
         assert sb.bounce_launches == depth
 
 
+def _skip_stress_scene(seed):
+    """Scenes built around Prim::self_r2: spheres far smaller than the rays that reach them are long (the reference's sphere quadratic
+    then reports hit points INSIDE the sphere by more than its 0.0002 bias, and the path bounces on inside -- the oracle renders
+    exactly that), mirror and diffuse, beside ellipsoids, huge and far-away primitives, thin slabs, overlapping pairs."""
+    rng = np.random.default_rng(seed)
+    mats = [O.make_material(color=rng.uniform(0.3, 1.0, 3)),                       # (the layout of _random_scene: tests/fuzz_gpu.py edits 1 and 3)
+            O.make_material(color=rng.uniform(0.3, 1.0, 3)),
+            O.make_material(color=(0.9, 0.9, 0.9), spec=(1, 1, 1), refl=1.0),
+            O.make_material(color=(0, 0, 0), spec=(1, 1, 1), refr=1.0, ior=1.5),
+            O.make_material(color=(1, 1, 1), emittance=8.0)]
+    room = float(rng.choice([12.0, 40.0, 110.0, 300.0]))
+    geoms = [O.make_geom(O.CUBE, 0, (0, 0, 0), (0, 0, 0) if seed % 2 else rng.uniform(-3, 3, 3), (room, room, room)),
+             O.make_geom(O.CUBE, 4, (0, room * 0.45, 0), (0, 0, 0), (room * 0.4, 0.05 * room, room * 0.4))]
+    ats = []
+    for i in range(int(rng.integers(6, 28))):
+        kind = O.SPHERE if rng.random() < 0.7 else O.CUBE
+        r = rng.random()
+        if r < 0.5:   s = np.full(3, rng.uniform(0.01, 0.3))                # tiny
+        elif r < 0.6: s = np.full(3, rng.uniform(0.3, 3.0)) * (1.0 + rng.uniform(-2e-6, 2e-6, 3))     # almost uniform
+        elif r < 0.7: s = rng.uniform(0.05, 2.0, 3)                         # ellipsoid / brick
+        elif r < 0.8: s = np.array([rng.uniform(1, 4), 0.004, rng.uniform(1, 4)])   # thin slab
+        elif r < 0.9: s = np.full(3, rng.uniform(60.0, 70.0) if room > 100 else rng.uniform(2.0, 5.0))
+        else:         s = np.full(3, rng.uniform(0.3, 1.5))
+        at = rng.uniform(-0.42, 0.42, 3) * room
+        ats.append(at)
+        geoms.append(O.make_geom(kind, int(rng.integers(0, 4)), at, rng.uniform(-3.2, 3.2, 3), s))
+        if rng.random() < 0.2:                                                # a second one through the first
+            geoms.append(O.make_geom(kind, int(rng.integers(0, 4)), at + rng.uniform(-0.5, 0.5, 3) * s, rng.uniform(-3.2, 3.2, 3), s))
+    eye = rng.uniform(-0.3, 0.3, 3) * room
+    tgt = ats[int(rng.integers(0, len(ats)))]
+    view = tgt - eye
+    view = view / np.linalg.norm(view) if np.linalg.norm(view) > 1e-3 else np.array([0, 0, -1.0])
+    up = np.cross(view, rng.normal(size=3))
+    up /= np.linalg.norm(up)
+    return geoms, mats, eye, view, up, float(rng.uniform(4, 30))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_resident_paths_self_skip_stress(pkg, seed):
+    """A resident path that leaves a convex primitive on its outside skips that primitive at its next bounce -- only where the
+    reference's own arithmetic would miss it too (Prim::self_r2; DESIGN.md 5.1).  Scenes aimed at the places where it would not."""
+    geoms, mats, eye, view, up, fovy = _skip_stress_scene(7000 + seed)
+    W, H, depth, iters = 96, 54, 14, 3
+    ga = (O.StaticGeom * len(geoms))(*geoms)
+    ma = (O.Material * len(mats))(*mats)
+    cam = O.make_camera(W, H, eye, view, up, fovy)
+    ref, live = O.render(ga, len(geoms), ma, len(mats), cam, depth, iters=iters, rr_start=-1, seed=seed)
+    for geom_path in (5, 7, 8, 1):                              # pair queue, batched walks (resident), per-primitive loop (launch per bounce)
+        with pkg.Renderer(0) as r:
+            r.set_options(depth=depth, seed=seed, geom_path=geom_path, resident=1, batch=3)
+            r.set_scene(C.cast(ga, C.POINTER(pkg.StaticGeom)), len(geoms), C.cast(ma, C.POINTER(pkg.Material)), len(mats))
+            r.set_camera(pkg.CameraData.from_buffer_copy(cam))
+            r.clear_image()
+            r.render(1, iters)
+            img = r.download_image()
+            st = r.stats()
+            info = r.launch_info()
+        check(img, ref, [int(x) for x in st.live_in[:depth]], [int(x) for x in live], f"self-skip stress {seed} geom_path={geom_path}")
+        assert info.resident == (0 if geom_path == 1 else 1), (seed, geom_path)
+
+
 @pytest.mark.parametrize("scene,depth,opts", [
     ("sampleScene_spec.txt", 6, {"direct_light": 1}),                                   # shadow-ray pass inside the resident loop
     ("sampleScene_spec.txt", 8, {"direct_light": 1, "rr_start": 2, "batch": 3}),
