@@ -671,10 +671,33 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
         const float4 n4 = s_boxes[16 * g + octoff], f4 = s_boxes[16 * g + octoff + 1];
         const float tn = fmaxf(fmaxf(__builtin_fmaf(n4.x, dinv.x, oinv.x), __builtin_fmaf(n4.y, dinv.y, oinv.y)),
                                fmaxf(__builtin_fmaf(n4.z, dinv.z, oinv.z), n4.w));
-        const float tf = fminf(fminf(__builtin_fmaf(f4.x, dinv.x, oinv.x), __builtin_fmaf(f4.y, dinv.y, oinv.y)),
-                               __builtin_fmaf(f4.z, dinv.z, oinv.z));
+        float tf = fminf(fminf(__builtin_fmaf(f4.x, dinv.x, oinv.x), __builtin_fmaf(f4.y, dinv.y, oinv.y)),
+                         __builtin_fmaf(f4.z, dinv.z, oinv.z));
+        float tnn = tn;
+        const float tf_box = tf;
+        static_assert(sizeof(PR) == 144, "the slab sits in the pad of the records' LDS copies");
+        // a tilted cube fills little of its world box: the ray is also clipped against the slab between the two faces of the cube's thinnest
+        // axis (host: KParams::slab_mask; planes n.x = d_lo / d_hi, n and d_lo in the pad of the record's LDS copy, d_hi in the far entry's w)
+        if (!MOTION && (uint32_t)g < 32u && ((p.slab_mask >> (uint32_t)g) & 1u) != 0u) {              // wave-uniform
+            const float4 s4 = reinterpret_cast<const float4 *>(&s_prims[g])[8];
+            const float nd = __builtin_fmaf(s4.z, d.z, __builtin_fmaf(s4.y, d.y, s4.x * d.x));
+            const float no = __builtin_fmaf(s4.z, o.z, __builtin_fmaf(s4.y, o.y, s4.x * o.x));
+            const float ri = __builtin_amdgcn_rcpf(nd);        // (nd = 0: +-inf -- a ray inside the slab keeps (-inf, inf), one outside gets an empty range)
+            const float ta = (s4.w - no) * ri, tb = (f4.w - no) * ri;
+            tnn = fmaxf(tnn, fminf(ta, tb));
+            tf = fminf(tf, fmaxf(ta, tb));
+        }
         // the compare's lane mask straight from v_cmp, and back into a predicate without VALU work
-        uint64_t mask = __builtin_amdgcn_fcmpf(tn, tf, FCMP_OLE) & vmask;
+        uint64_t mask = __builtin_amdgcn_fcmpf(tnn, tf, FCMP_OLE) & vmask;
+        if (DEBUG_BOUNDS && !MOTION) {
+            // (bounds-checking build: the exact test of every pair the slab turned away; a hit is reported)
+            const uint64_t turned = (__builtin_amdgcn_fcmpf(tn, tf_box, FCMP_OLE) & vmask) & ~mask;
+            if (turned != 0ull) {
+                f3 ip, in;
+                const float ts = __builtin_amdgcn_inverse_ballot_w64(turned) ? intersectPrim<false>(s_prims[g], o, d, o, ip, in) : -1.0f;
+                if (ts > 0.0f) dbgInRange(p, 43, (unsigned long long)g + 1000ull, 0ull);
+            }
+        }
         if (SKIP) {
             const uint64_t own = __builtin_amdgcn_uicmp(skip, (uint32_t)g, 32 /* ICMP_EQ */);      // lanes whose ray just left primitive g
             if (DEBUG_BOUNDS && (mask & own) != 0ull) {
@@ -1317,6 +1340,8 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
         const uint4 *src = reinterpret_cast<const uint4 *>(p.prims);
         uint4 *dst = reinterpret_cast<uint4 *>(s_prims);
         for (int k = tid; k < p.nG * 8; k += WG) dst[(k >> 3) * 9 + (k & 7)] = src[k];
+        if (GEOM == GEOM_PAIR)                                // ... and in the pad the pre-test's slab (n.xyz, d_lo)
+            for (int k = tid; k < p.nG; k += WG) dst[k * 9 + 8] = reinterpret_cast<const uint4 *>(p.slab_n)[k];
         const uint4 *fsrc = reinterpret_cast<const uint4 *>(p.face_n);
         for (int k = tid; k < p.nG * 8; k += WG) dst[p.nG * 9 + (k >> 3) * 9 + (k & 7)] = fsrc[k];
     }
@@ -1330,7 +1355,7 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
                 const uint4 lo = from[2 * (k >> 3)], hi = from[2 * (k >> 3) + 1];
                 const int oc = k & 7;
                 to[2 * k] = make_uint4((oc & 1) ? hi.x : lo.x, (oc & 2) ? hi.y : lo.y, (oc & 4) ? hi.z : lo.z, 0u);
-                to[2 * k + 1] = make_uint4((oc & 1) ? lo.x : hi.x, (oc & 2) ? lo.y : hi.y, (oc & 4) ? lo.z : hi.z, 0u);
+                to[2 * k + 1] = make_uint4((oc & 1) ? lo.x : hi.x, (oc & 2) ? lo.y : hi.y, (oc & 4) ? lo.z : hi.z, hi.w);     // (w: the slab's d_hi)
             }
         };
         stage_oct(src, dst);

@@ -107,6 +107,7 @@ struct pt_ctx {
     uint32_t *d_span_mask = nullptr;
     size_t span_mask_cap = 0;
     float *d_box_world = nullptr;
+    float *d_slab_n = nullptr;          // per primitive (n.xyz, d_lo) of the pre-test's slab (KParams::slab_mask)
     pt::LightRec *d_lights = nullptr;    // direct lighting: the light table
     float *d_knots = nullptr, *d_knot_cam = nullptr;   // per-ray motion blur: knot states (matrices, camera vectors)
     int *d_light_tris = nullptr;         //   mesh lights: triangle numbers ...
@@ -817,12 +818,50 @@ int configure(pt_ctx *c)
 
         // ... and a wave of camera rays covers a small solid angle: the padded world box of every primitive,
         // relative to the eye, lets a wave skip the primitives none of its rays can reach (culling only)
-        std::vector<float> be(prims.size() * 8, 0.0f), bw(prims.size() * 8, 0.0f);
+        std::vector<float> be(prims.size() * 8, 0.0f), bw(prims.size() * 8, 0.0f), slab_n(prims.size() * 4, 0.0f);
+        uint32_t slab_mask = 0u;
         for (size_t i = 0; i < nP; ++i) {
             // hit-or-miss culling only (no distance pruning): the padding just has to cover fp32 rounding (1e-6 of the
             // coordinates), and a tight one keeps a ray that leaves a wall (0.0002 above it) outside that wall's box
             const Aabb b = i < nGeoms ? prim_bounds(c->geoms[i], 1.005, 1e-4, reach[i]) : tri_bounds(i - nGeoms, 1.005, 1e-4);
             for (int a = 0; a < 3; ++a) { bw[8 * i + (size_t)a] = b.lo[a]; bw[8 * i + 4 + (size_t)a] = b.hi[a]; }
+            // a TILTED cube fills little of its world box (the bundled scene's walls, with ROTAT read as radians: 10 x 0.01 x 10 slabs at
+            // arbitrary angles, whose boxes fill the room): the pre-test also clips the ray against the slab between the two faces of the
+            // cube's THINNEST axis, planes n.x = d_lo / d_hi (n in the record's LDS pad, d_lo beside it, d_hi in the far entry's w).
+            // Padded like the box (0.5 % + 1e-4 + what the reference's slab arithmetic errs by, 2e-6 x reach, + the rounding of n.o).
+            if (i < nGeoms && i < 32 && c->geoms[i].type == PT_CUBE && !getenv("PT_NO_SLAB")) {
+                const pt_mat4 &m = c->geoms[i].transform;
+                const float *r0 = &m.x.x, *r1 = &m.y.x, *r2 = &m.z.x;
+                double col[3][3], len[3];
+                for (int j = 0; j < 3; ++j) {
+                    col[j][0] = r0[j]; col[j][1] = r1[j]; col[j][2] = r2[j];
+                    len[j] = sqrt(col[j][0] * col[j][0] + col[j][1] * col[j][1] + col[j][2] * col[j][2]);
+                }
+                bool orth = len[0] > 0.0 && len[1] > 0.0 && len[2] > 0.0;
+                for (int a = 0; a < 3 && orth; ++a)
+                    for (int b2 = a + 1; b2 < 3; ++b2)
+                        if (!(fabs(col[a][0] * col[b2][0] + col[a][1] * col[b2][1] + col[a][2] * col[b2][2]) <= 1e-5 * len[a] * len[b2])) orth = false;
+                const double vbox = ((double)b.hi[0] - b.lo[0]) * ((double)b.hi[1] - b.lo[1]) * ((double)b.hi[2] - b.lo[2]);
+                const int t = len[0] <= len[1] ? (len[0] <= len[2] ? 0 : 2) : (len[1] <= len[2] ? 1 : 2);
+                // (worth its dozen and a half instructions per ray and trip only where the slab is a small part of the box: 0.25 below)
+                const double hx = 0.5 * ((double)b.hi[0] - b.lo[0]), hy = 0.5 * ((double)b.hi[1] - b.lo[1]), hz = 0.5 * ((double)b.hi[2] - b.lo[2]);
+                if (orth && std::isfinite(vbox) && vbox > 0.0) {
+                    const double n[3] = {col[t][0] / len[t], col[t][1] / len[t], col[t][2] / len[t]};
+                    const double cc[3] = {m.x.w, m.y.w, m.z.w};
+                    const double nc = n[0] * cc[0] + n[1] * cc[1] + n[2] * cc[2];
+                    const double coord = fabs(cc[0]) + fabs(cc[1]) + fabs(cc[2]) + hx + hy + hz;      // |n.o| of any origin that matters is below this + reach
+                    const double half = 0.5 * len[t] * 1.005 + 1e-4 + 2e-6 * reach[i] + 4e-7 * (coord + reach[i]);
+                    // the box's extent along n: the slab only helps where it is much thinner than that
+                    const double ext = fabs(n[0]) * hx + fabs(n[1]) * hy + fabs(n[2]) * hz;
+                    if (half < 0.25 * ext) {
+                        slab_n[4 * i + 0] = (float)n[0]; slab_n[4 * i + 1] = (float)n[1]; slab_n[4 * i + 2] = (float)n[2];
+                        // (n rounded to fp32 tilts the planes by <= 1e-7 rad: <= 1e-7 x the cube's size across its faces, inside the pad)
+                        slab_n[4 * i + 3] = (float)(nc - half);
+                        bw[8 * i + 7] = (float)(nc + half);
+                        slab_mask |= 1u << i;
+                    }
+                }
+            }
             const double e[3] = {c->cam.position.x, c->cam.position.y, c->cam.position.z};
             for (int a = 0; a < 3; ++a) {
                 const double lo = (double)b.lo[a] - e[a], hi = (double)b.hi[a] - e[a];
@@ -830,7 +869,13 @@ int configure(pt_ctx *c)
                 be[8 * i + (size_t)a] = (float)(lo - pad);
                 be[8 * i + 4 + (size_t)a] = (float)(hi + pad);
             }
+            be[8 * i + 7] = bw[8 * i + 7];                  // (the slab's planes stay in world space: the kernel forms n.o for camera rays too)
         }
+        k.slab_mask = slab_mask;
+        if (c->d_slab_n) { (void)hipFree(c->d_slab_n); c->d_slab_n = nullptr; }
+        HIP_TRY(hipMalloc((void **)&c->d_slab_n, slab_n.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(c->d_slab_n, slab_n.data(), slab_n.size() * sizeof(float), hipMemcpyHostToDevice));
+        k.slab_n = c->d_slab_n;
         c->h_box_eye = be;
         if (c->d_box_eye) { (void)hipFree(c->d_box_eye); c->d_box_eye = nullptr; }
         HIP_TRY(hipMalloc((void **)&c->d_box_eye, be.size() * sizeof(float)));
@@ -907,6 +952,7 @@ int configure(pt_ctx *c)
         if (!kn.empty()) HIP_TRY(hipMemcpy(c->d_knots, kn.data(), kn.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_knot_cam, kc.data(), kc.size() * sizeof(float), hipMemcpyHostToDevice));
         if (!swept.empty()) HIP_TRY(hipMemcpy(c->d_box_world, swept.data(), swept.size() * sizeof(float), hipMemcpyHostToDevice));
+        k.slab_mask = 0u;                                    // (a moving cube's slab moves with it)
         k.knots = c->d_knots;
         k.knot_cam = c->d_knot_cam;
         k.nknots = nk;
@@ -1610,6 +1656,7 @@ void pt_destroy(pt_ctx *c)
     if (c->d_box_eye) (void)hipFree(c->d_box_eye);
     if (c->d_span_mask) (void)hipFree(c->d_span_mask);
     if (c->d_box_world) (void)hipFree(c->d_box_world);
+    if (c->d_slab_n) (void)hipFree(c->d_slab_n);
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_light_tris) (void)hipFree(c->d_light_tris);
     if (c->d_light_cdf) (void)hipFree(c->d_light_cdf);

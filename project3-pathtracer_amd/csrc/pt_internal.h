@@ -90,6 +90,8 @@ struct KParams {
     int eye_cull;          // 1 = camera-ray waves skip primitives outside their boxes (box_eye), ablation switch
     const float *box_world; // per primitive: padded world box (lo.xyz,0)(hi.xyz,0): per-lane pre-test of the pair queue
     const float *box_eye;  // per primitive: padded world box minus the eye, (lo.xyz,0)(hi.xyz,0): wave cull of camera rays
+    const float *slab_n;   // pair path: per primitive (n.xyz, d_lo) of the slab the pre-test clips rays of tilted cubes against (d_hi: box[7])
+    uint32_t slab_mask;    // bit g: primitive g (< 32) has such a slab
     const uint32_t *span_off;   // batched walks, camera rays: per span (offset, count) into span_list; count 0xFFFFFFFF = walk (nullptr: no lists)
     const uint32_t *span_list;  // primitive indices
     const uint32_t *span_mask;  // pair path, camera rays: per 64 tile-local pixels, bit g = primitive g can be seen from them (nullptr: no table)
