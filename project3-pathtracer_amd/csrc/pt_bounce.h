@@ -538,7 +538,18 @@ struct PairQueue {
     f3 po, pd;                    // org == nullptr (batched walk): the calling lane's OWN ray; a pair's lane fetches its owner's
                                   // through ds_bpermute instead of from an LDS copy (1.5 KB per wave less)
     uint2 *mt;                    // [64] per owner lane (FEAT_MOTION only): the ray's shutter segment and fraction (MotionTime)
+    uint32_t *wait;               // [64] per owner lane (resident pair kernels only, same LDS as mt): scratch of the carry-over below
     unsigned long long *dbg;
+};
+// Resident pair kernels: what a wave's pair queues keep from one trip of its loop to the next.  A trip of the bundled scene queues
+// about as many pairs as a batch has lanes (~ 67 for ~ 60 rays): one batch is full, a second one would run the whole exact test for a
+// handful of lanes.  Those few pairs stay queued instead (`carry_max` of them at most), their owners sit the trip's shading out --
+// paths are independent, a lane simply keeps its path one trip longer -- and the next trip's first batch takes them along.  A pair
+// waits one trip at most: whatever was carried is tested before the next trip ends.
+// (Only box pairs are carried -- the mixed batch takes every sphere pair -- so the state is one word and a lane mask.)
+struct PairCarry {
+    uint32_t st = 0u;                                     // wave-uniform: where the box queue's carried pairs start (bits 0..7) | how many (bits 8..)
+    uint64_t wait = 0ull;                                 // lanes whose path waits for carried pairs
 };
 static constexpr uint32_t PAIR_QUEUE_BYTES = 2 * QCAP * 4 + 64 * 8 + 2 * 64 * 16 + 64 * 8;
 // LDS bytes per primitive of the pre-test's box table: eight (near, far) entries, one per direction octant
@@ -633,19 +644,25 @@ __device__ __forceinline__ void pairBatch(const KParams &p, const PR *s_prims, c
 // primitives the host marks: Prim::self_r2, pt_context.hip) -- but its origin lies inside the primitive's padded box, so the pre-test
 // would queue the pair every time: on the bundled scene, whose walls are tilted (ROTAT in radians) and fill the room with their
 // boxes, HALF of all pairs were such self pairs.  The bounds-checking build runs the exact test on every skipped pair and reports a hit.
-template <bool FIRST, class PR, bool MOTION = false, bool SKIP = false>
+template <bool FIRST, class PR, bool MOTION = false, bool SKIP = false, bool CARRY = false>
 __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_prims, const float4 *s_boxes, const PairQueue q,
                                                f3 o, f3 d, bool valid, uint32_t lane, uint32_t primmask, MotionTime mymt = MotionTime(),
-                                               uint32_t skip = 0xFFFFFFFFu)
+                                               uint32_t skip = 0xFFFFFFFFu, PairCarry *pc = nullptr)
 {
     const unsigned long long ph_in = LANE_BUDGET<FIRST>() ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long fb_clk = 0ull, lb_lane_clk = 0ull;      // DEBUG_PHASE2: clocks inside full batches; lane-clocks of the last batches
-    q.key[lane] = KEY_NONE;
-    q.org[lane] = make_float4(o.x, o.y, o.z, d.x);
-    q.dir[lane] = make_float2(d.y, d.z);
+    // CARRY: lanes whose path waits for pairs carried over from the last trip keep their key, ray and queue entries
+    const bool fresh = CARRY ? !__builtin_amdgcn_inverse_ballot_w64(pc->wait) : true;
+    if (fresh) {
+        q.key[lane] = KEY_NONE;
+        q.org[lane] = make_float4(o.x, o.y, o.z, d.x);
+        q.dir[lane] = make_float2(d.y, d.z);
+    }
     if (MOTION) q.mt[lane] = make_uint2(mymt.k, __float_as_uint(mymt.f));
     uint32_t head[2] = {0u, 0u}, tail[2] = {0u, 0u};        // wave-uniform
-    const uint64_t vmask = __ballot(valid);
+    if (CARRY) { head[1] = pc->st & 0xFFu; tail[1] = head[1] + (pc->st >> 8); }
+    const uint32_t old_end0 = 0u, old_end1 = tail[1];        // CARRY: the carried pairs end here
+    const uint64_t vmask = CARRY ? (__ballot(valid) & ~pc->wait) : __ballot(valid);
     const f3 dinv = approxInverse(d);
     // slab distances as fma(plane, 1/d, -o/d): one instruction per plane; against (plane - o)/d this moves a plane by
     // less than 1.2e-6 |o|, far inside the boxes' padding
@@ -730,17 +747,37 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
             }
         }
     }
-    const uint64_t dbg_valid = DEBUG_PAIR ? __ballot(valid) : 0ull;
     if (DEBUG_PAIR && lane == 0) {
-        atomicAdd(&p.st->dbg[0], (unsigned long long)tail[0]);
-        atomicAdd(&p.st->dbg[1], (unsigned long long)tail[1]);
-        atomicAdd(&p.st->dbg[4], (unsigned long long)__popcll(dbg_valid));
-        atomicAdd(&p.st->dbg[5], (unsigned long long)((tail[0] + 63) / 64 + (tail[1] + 63) / 64));
+        atomicAdd(&p.st->dbg[0], (unsigned long long)(tail[0] - old_end0));
+        atomicAdd(&p.st->dbg[1], (unsigned long long)(tail[1] - old_end1));
+        atomicAdd(&p.st->dbg[4], (unsigned long long)__popcll(vmask));
+        atomicAdd(&p.st->dbg[5], (unsigned long long)((tail[0] - old_end0 + 63) / 64 + (tail[1] - old_end1 + 63) / 64));
         atomicAdd(&p.st->dbg[6], 1ull);
     }
     const unsigned long long ph_a = LANE_BUDGET<FIRST>() ? __builtin_amdgcn_s_memtime() : 0ull;
     const uint32_t left0 = tail[0] - head[0], left1 = tail[1] - head[1];      // both < 64
-    if (left0 != 0u && left1 != 0u && left0 + left1 <= 64u) {
+    uint64_t waitnow = 0ull;                                                   // CARRY: lanes whose pairs stay queued
+    bool handled = false;
+    if (CARRY && p.carry_max > 0) {
+        // carried pairs not yet taken by a full batch of this trip: they must go now
+        const uint32_t old1 = (int32_t)(old_end1 - head[1]) > 0 ? old_end1 - head[1] : 0u;
+        const uint32_t total = left0 + left1;
+        if (total > 64u && total - 64u <= (uint32_t)p.carry_max && old1 <= 64u - left0) {
+            // one full mixed batch -- every sphere pair, box pairs up to 64 lanes -- and the few box pairs beyond it wait
+            pairBatch<2u, FIRST, PR, MOTION>(p, s_prims, q, head[0], left0, lane, head[1], 64u - left0);
+            head[0] += left0; head[1] += 64u - left0;
+            const uint32_t c1 = total - 64u;
+            handled = true;
+            // their owners: flags in LDS, set by the lanes that read the carried entries
+            q.wait[lane] = 0u;
+            wave_lds_fence();
+            if (lane < c1) q.wait[q.q[1][(head[1] + lane) & (QCAP - 1u)] & 63u] = 1u;
+            wave_lds_fence();
+            waitnow = __ballot(q.wait[lane] != 0u);
+        }
+    }
+    if (handled) {
+    } else if (left0 != 0u && left1 != 0u && left0 + left1 <= 64u) {
         pairBatch<2u, FIRST, PR, MOTION>(p, s_prims, q, head[0], left0, lane, head[1], left1);   // one mixed batch instead of two partial ones
         if (LANE_BUDGET<FIRST>()) lb_lane_clk += (__builtin_amdgcn_s_memtime() - ph_a) * (unsigned long long)(left0 + left1);
     } else {
@@ -749,6 +786,12 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
         if (LANE_BUDGET<FIRST>()) lb_lane_clk += (ph_b - ph_a) * (unsigned long long)left0;
         if (left1 != 0u) pairBatch<1u, FIRST, PR, MOTION>(p, s_prims, q, head[1], left1, lane);
         if (LANE_BUDGET<FIRST>()) lb_lane_clk += (__builtin_amdgcn_s_memtime() - ph_b) * (unsigned long long)left1;
+    }
+    if (CARRY) {
+        if (!handled) head[1] = tail[1];
+        pc->st = (head[1] & (QCAP - 1u)) | ((tail[1] - head[1]) << 8);
+        pc->wait = waitnow;
+        if (__builtin_amdgcn_inverse_ballot_w64(waitnow)) valid = false;       // (no result yet for a path that waits)
     }
     wave_lds_fence();
     Hit h;
@@ -1213,10 +1256,10 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
 
 // nearest hit of (o, d) for the lanes with want == true, by the GEOM path.  Every lane of the wave must make the call
 // (the hit queue uses all 64 lanes as workers whatever their own ray).
-template <int GEOM, bool FIRST, bool MOTION = false, bool SKIP = false>
+template <int GEOM, bool FIRST, bool MOTION = false, bool SKIP = false, bool CARRY = false>
 __device__ __forceinline__ Hit nearestHit(const KParams &p, const PrimPad *s_prims, const float4 *s_nodes, const WaveQueue &wq,
                                           f3 o, f3 d, bool want, uint32_t lane, uint32_t primmask = 0xFFFFFFFFu, MotionTime mt = MotionTime(),
-                                          uint32_t skip = 0xFFFFFFFFu)
+                                          uint32_t skip = 0xFFFFFFFFu, PairCarry *pc = nullptr)
 {
     if (GEOM == GEOM_QUEUE) return nearestHitQueued<FIRST>(p, s_prims, wq, o, d, want, lane);
     if (GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR || GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) {
@@ -1229,6 +1272,7 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const PrimPad *s_pri
         pq.org = reinterpret_cast<float4 *>(b + 2 * QCAP * 4 + 64 * 8 + 64 * 16);
         pq.dir = reinterpret_cast<float2 *>(b + 2 * QCAP * 4 + 64 * 8 + 2 * 64 * 16);
         pq.mt = reinterpret_cast<uint2 *>(b + PAIR_QUEUE_BYTES);           // (carved for FEAT_MOTION instances only)
+        pq.wait = reinterpret_cast<uint32_t *>(b + PAIR_QUEUE_BYTES);      // (... and for the resident pair kernels)
         pq.dbg = p.st->dbg;
         pq.tq = nullptr;
         if (GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) {
@@ -1243,7 +1287,7 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const PrimPad *s_pri
             return nearestHitWalk4<FIRST, SKIP>(p, p.prims, w4, pq, o, d, want, lane, (FIRST && p.span_off != nullptr) ? primmask : 0xFFFFFFFFu, skip);
         }
         if (GEOM == GEOM_WALK_PAIR) return nearestHitWalkPairs<FIRST>(p, p.prims, s_nodes, pq, o, d, want, lane);
-        return nearestHitPairs<FIRST, PrimPad, MOTION, SKIP>(p, s_prims, s_nodes, pq, o, d, want, lane, primmask, mt, skip);
+        return nearestHitPairs<FIRST, PrimPad, MOTION, SKIP, CARRY && GEOM == GEOM_PAIR>(p, s_prims, s_nodes, pq, o, d, want, lane, primmask, mt, skip, pc);
     }
     Hit h;
     h.any = false;
@@ -1313,7 +1357,7 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
                                                  : (GEOM == GEOM_PAIR ? p.nG * PAIR_BOX_BYTES * (NEE ? 2 : 1) : 0));
     unsigned char *s_queue = smem + prim_bytes + node_bytes;
     const int WAVE_LDS = (GEOM == GEOM_QUEUE) ? (int)WAVE_QUEUE_BYTES
-                         : ((GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR) ? (int)((MOTION && GEOM == GEOM_PAIR) ? PAIR_QUEUE_MOTION_BYTES : PAIR_QUEUE_BYTES)
+                         : ((GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR) ? (int)(((MOTION || RESIDENT) && GEOM == GEOM_PAIR) ? PAIR_QUEUE_MOTION_BYTES : PAIR_QUEUE_BYTES)
                             : ((GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) ? (int)walk4_wave_bytes(p.ntri) : 0));
     const int queue_bytes = NW * WAVE_LDS;
     float *s_mats = reinterpret_cast<float *>(s_queue + queue_bytes);
@@ -1514,6 +1558,9 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
             wflags = (wflags & ~WF_SHARD) | ((rot + (uint32_t)__builtin_ctz(m)) & WF_SHARD);
         }
     };
+    // resident pair kernels without shadow rays (those share the queues): leftover pairs of a trip may wait for the next one's batch
+    constexpr bool CARRY = RESIDENT && GEOM == GEOM_PAIR && !NEE && !MEDIA;
+    PairCarry carry;
     // RESIDENT: the path a lane carries from one trip of the loop to the next (else: this trip's ray)
     bool valid = false;
     f3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(1, 1, 1);
@@ -1696,10 +1743,13 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
             h.any = false; h.material = 0; h.prim = 0; h.t = 0.0f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0);
             if (valid) h = nearestHitMotion(p, o, d, mt);
         } else {
-            if (RESIDENT) h = nearestHit<GEOM, false, false, true>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane, 0xFFFFFFFFu, MotionTime(), (lb >> 8) - 1u);
+            if (RESIDENT) h = nearestHit<GEOM, false, false, true, CARRY>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane, 0xFFFFFFFFu, MotionTime(), (lb >> 8) - 1u, &carry);
             else h = (FIRST && p.lens_radius > 0.0f) ? nearestHit<GEOM, false>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane)
                                                      : nearestHit<GEOM, FIRST>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane, primmask);
         }
+        // CARRY: a path whose last pairs stay queued for the next trip's batch sits this trip's shading out
+        const bool held = CARRY ? (valid && __builtin_amdgcn_inverse_ballot_w64(carry.wait)) : false;
+        if (CARRY) valid = valid && !held;
         const unsigned long long c2 = (DEBUG_PHASE || PT_DEBUG_PHASE == 2 || PT_DEBUG_PHASE == 3) ? __builtin_amdgcn_s_memtime() : 0ull;
         if (LANE_BUDGET<FIRST>()) { lb_nvalid = (uint32_t)__popcll(__ballot(valid)); lb_nhit = (uint32_t)__popcll(__ballot(valid && h.any)); }
         bool did_bsdf = false;            // (DEBUG_PHASE2)
@@ -1979,8 +2029,8 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
             // a path that ended is counted at the bounce it ended at (the per-bounce live counts follow from the histogram);
             // one that goes on stays where it is, a bounce further
             if (valid && !alive) atomicAdd(&s_term[cb], 1u);
-            valid = alive;
-            lb = (cb + 1u) | (leaves_outside ? ((h.prim + 1u) << 8) : 0u);
+            valid = alive || held;
+            if (!held) lb = (cb + 1u) | (leaves_outside ? ((h.prim + 1u) << 8) : 0u);
             if (DEBUG_PHASE2 && GEOM == GEOM_PAIR) { const unsigned long long c4 = __builtin_amdgcn_s_memtime() - c3; lbud[11] += c4; lbud[12] += c4 * (unsigned long long)__popcll(__ballot(alive)); }
             continue;
         }

@@ -21,6 +21,9 @@
 #ifndef PT_RESIDENT_DEFAULT
 #define PT_RESIDENT_DEFAULT 1
 #endif
+#ifndef PT_CARRY_MAX_DEFAULT
+#define PT_CARRY_MAX_DEFAULT 8
+#endif
 #ifndef PT_REFILL_MIN_DEFAULT
 #define PT_REFILL_MIN_DEFAULT 8
 #endif
@@ -621,7 +624,8 @@ int configure(pt_ctx *c)
             if (orthogonal) rad = (g.type == PT_SPHERE) ? 0.5 * maxlen : 0.5 * sqrt(sumsq);   // r*s_max / half diagonal
             else rad = (g.type == PT_SPHERE) ? 0.5 * sqrt(sumsq) : 0.5 * sum;                  // Frobenius / triangle bound
             if (g.type == PT_SPHERE) rad *= sphere_noise_factor(g, reach[i]);                  // (what the reference's test hits)
-            rad = rad * 1.02 + 1e-3 + 2e-6 * reach[i];
+            // (+ what the reference's inverseTransform * origin and the cull's own c - o lose far from the world origin)
+            rad = rad * 1.02 + 1e-3 + 2e-6 * reach[i] + 4e-6 * (fabs((double)p.cx) + fabs((double)p.cy) + fabs((double)p.cz));
             p.bound_r2 = (float)(rad * rad);
             // self_r2: may a ray that leaves this primitive on its OUTSIDE skip it at its next bounce (resident paths)?  Mathematically a
             // ray that starts outside a convex primitive and moves away from it cannot meet it again; the kernels may only rely on
@@ -1102,6 +1106,9 @@ int configure(pt_ctx *c)
         k.refill_min = getenv("PT_REFILL_MIN") ? atoi(getenv("PT_REFILL_MIN")) : PT_REFILL_MIN_DEFAULT;
         if (k.refill_min < 1) k.refill_min = 1;
         if (k.refill_min > 64) k.refill_min = 64;
+        k.carry_max = getenv("PT_CARRY_MAX") ? atoi(getenv("PT_CARRY_MAX")) : PT_CARRY_MAX_DEFAULT;
+        if (k.carry_max < 0) k.carry_max = 0;
+        if (k.carry_max > 48) k.carry_max = 48;
     }
     size_t lds = pt::bounce_lds_bytes(k, cfg);
     if ((cfg.geom == 6 || cfg.geom == 7) && o.workgroup == 0) {
@@ -1208,6 +1215,23 @@ int configure(pt_ctx *c)
         auto dirOf = [&](double sx, double sy, double *o3) {
             for (int a = 0; a < 3; ++a) o3[a] = vw[a] + (1.0 - 2.0 * sx) * (double)k.H[a] + (1.0 - 2.0 * sy) * (double)k.V[a];
         };
+        // The reference forms the point on the image plane in fp32 WORLD coordinates, (M + a H) + b V with M = eye + view, and only then
+        // subtracts the eye: far from the world origin the ray directions are quantised to the ulp of the eye's coordinates (an eye at
+        // 3e6 sees a 0.25-unit grid through a 1-unit view vector) and leave the ideal pixel frustum by far more than a pixel.  Each
+        // component of P - eye errs by <= ~ 3 ulp of the largest coordinate involved; in screen units that is a margin of
+        // err / (2 |H|) and err / (2 |V|) on top of the pixel the frustum is grown by.  Past a full screen of margin: no culling.
+        double sx_margin, sy_margin;
+        {
+            double big = 0.0, lh = 0.0, lv = 0.0;
+            for (int a = 0; a < 3; ++a) {
+                big = std::max(big, fabs(eye3[a]) + fabs(vw[a]) + fabs((double)k.H[a]) + fabs((double)k.V[a]));
+                lh += (double)k.H[a] * (double)k.H[a]; lv += (double)k.V[a] * (double)k.V[a];
+            }
+            const double err = 3.0 * 1.1920929e-7 * big * 1.7320508;           // (vector norm of three such components)
+            sx_margin = lh > 0.0 ? err / (2.0 * sqrt(lh)) : 1e30;
+            sy_margin = lv > 0.0 ? err / (2.0 * sqrt(lv)) : 1e30;
+        }
+        const bool ray_grid_ok = sx_margin < 1.0 && sy_margin < 1.0;          // (a NaN fails)
         struct Frustum { double nrm[4][3], cc[3], lcc; bool planes_ok, narrow; };
         auto frustumOf = [&](int sp) -> Frustum {
             Frustum f;
@@ -1217,13 +1241,13 @@ int configure(pt_ctx *c)
             int xa = (int)(g0 % (uint32_t)W), xb = (int)(g1 % (uint32_t)W);
             if (y0 != y1) { xa = 0; xb = W - 1; }
             const int ya = y0 < y1 ? y0 : y1, yb = y0 < y1 ? y1 : y0;
-            const double sx0 = ((double)xa - 1.0) / (double)k.resx, sx1 = ((double)xb + 2.0) / (double)k.resx;
-            const double sy0 = ((double)ya - 1.0) / (double)k.resy, sy1 = ((double)yb + 2.0) / (double)k.resy;
+            const double sx0 = ((double)xa - 1.0) / (double)k.resx - sx_margin, sx1 = ((double)xb + 2.0) / (double)k.resx + sx_margin;
+            const double sy0 = ((double)ya - 1.0) / (double)k.resy - sy_margin, sy1 = ((double)yb + 2.0) / (double)k.resy + sy_margin;
             double cn[4][3];
             dirOf(sx0, sy0, cn[0]); dirOf(sx1, sy0, cn[1]); dirOf(sx1, sy1, cn[2]); dirOf(sx0, sy1, cn[3]);
             dirOf(0.5 * (sx0 + sx1), 0.5 * (sy0 + sy1), f.cc);
-            f.planes_ok = true;
-            for (int e = 0; e < 4; ++e) {
+            f.planes_ok = ray_grid_ok;
+            for (int e = 0; e < 4 && f.planes_ok; ++e) {
                 const double *a3 = cn[e], *b3 = cn[(e + 1) & 3];
                 const double n3[3] = {a3[1] * b3[2] - b3[1] * a3[2], a3[2] * b3[0] - b3[2] * a3[0], a3[0] * b3[1] - b3[0] * a3[1]};
                 const double len = sqrt(n3[0] * n3[0] + n3[1] * n3[1] + n3[2] * n3[2]);

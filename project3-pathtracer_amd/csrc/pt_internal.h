@@ -124,6 +124,7 @@ struct KParams {
     int nknots;            // 0 = off
     float tan_x, tan_y;    // tan of the half field-of-view angles (the per-ray camera basis is built on the device)
     int refill_min;        // resident paths (FEAT_RESIDENT kernels): a wave refills its free lanes from the pool once this many are free
+    int carry_max;         // resident pair kernels: at most this many leftover pairs of a trip wait for the next trip's batch (0: none; PairCarry)
 };
 
 struct LaunchCfg {

@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O  # noqa: E402
 from __graft_entry__ import load_package  # noqa: E402
-from test_gpu_parity import _random_scene, _skip_stress_scene  # noqa: E402
+from test_gpu_parity import _extreme_scene, _random_scene, _skip_stress_scene  # noqa: E402
 
 
 def main():
@@ -54,6 +54,10 @@ def main():
             # are long: the culling bounds have to hold what the test HITS, and a resident path may only skip the primitive it leaves
             # where the test would miss it -- Prim::self_r2)
             geoms, mats, eye, view, up, fovy = _skip_stress_scene(5000 + case)
+            n_prims = len(geoms)
+        elif rng4.random() < 0.1:
+            # ... and scenes at the edges of fp32 (far from the origin, huge, tiny, needles, zero and negative scales)
+            geoms, mats, eye, view, up, fovy = _extreme_scene(("far", "huge", "tiny", "needle", "zero", "neg")[case % 6], 5000 + case)
             n_prims = len(geoms)
         if rng.random() < 0.4:
             opts["direct_light"] = 1

@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O  # noqa: E402
 from __graft_entry__ import load_package  # noqa: E402
-from test_gpu_parity import _random_scene, _skip_stress_scene  # noqa: E402
+from test_gpu_parity import _extreme_scene, _random_scene, _skip_stress_scene  # noqa: E402
 
 pkg = load_package()
 
@@ -36,6 +36,9 @@ def run(case, override):
     os.environ.setdefault("PT_REFILL_MIN", str(int(rng4.choice([1, 4, 16, 33, 64]))))
     if rng4.random() < 0.2:
         geoms, mats, eye, view, up, fovy = _skip_stress_scene(5000 + case)
+        n_prims = len(geoms)
+    elif rng4.random() < 0.1:
+        geoms, mats, eye, view, up, fovy = _extreme_scene(("far", "huge", "tiny", "needle", "zero", "neg")[case % 6], 5000 + case)
         n_prims = len(geoms)
     if rng.random() < 0.4:
         opts["direct_light"] = 1

@@ -1459,6 +1459,65 @@ def _skip_stress_scene(seed):
     return geoms, mats, eye, view, up, float(rng.uniform(4, 30))
 
 
+def _extreme_scene(kind, seed):
+    """Scenes at the edges of fp32: far from the world origin, huge, tiny, needle-shaped cubes, zero and negative scales (singular and
+    mirrored transforms: the reference's parser accepts them, its arithmetic then does what it does -- and so must every culling
+    bound and shortcut of the kernels)."""
+    rng = np.random.default_rng(seed)
+    mats = [O.make_material(color=rng.uniform(0.3, 1.0, 3)), O.make_material(color=rng.uniform(0.3, 1.0, 3)),
+            O.make_material(color=(0.9, 0.9, 0.9), spec=(1, 1, 1), refl=1.0),
+            O.make_material(color=(0, 0, 0), spec=(1, 1, 1), refr=1.0, ior=1.5), O.make_material(color=(1, 1, 1), emittance=8.0)]
+    off, room, unit = np.zeros(3), 12.0, 1.0
+    if kind == "far":
+        off = rng.uniform(-1, 1, 3) * float(rng.choice([300.0, 2000.0, 20000.0]))
+    if kind == "huge":
+        unit = float(rng.choice([1e3, 1e5]))
+    if kind == "tiny":
+        unit = float(rng.choice([1e-2, 1e-4]))
+    room *= unit
+    geoms = [O.make_geom(O.CUBE, 0, off, rng.uniform(-3, 3, 3), (room, room, room)),
+             O.make_geom(O.CUBE, 4, off + np.array([0, room * 0.45, 0]), (0, 0, 0), (room * 0.4, 0.05 * room, room * 0.4))]
+    for _ in range(int(rng.integers(5, 20))):
+        k = O.SPHERE if rng.random() < 0.5 else O.CUBE
+        s = rng.uniform(0.3, 3.0, 3) * unit
+        if kind == "needle":
+            s = np.array([rng.uniform(2, 8), 1e-4 * rng.uniform(1, 50), rng.uniform(0.01, 3)])[rng.permutation(3)]
+        if kind == "zero" and rng.random() < 0.4:
+            s[int(rng.integers(0, 3))] = 0.0
+        if kind == "neg" and rng.random() < 0.5:
+            s = s * rng.choice([-1.0, 1.0], 3)
+        geoms.append(O.make_geom(k, int(rng.integers(0, 4)), off + rng.uniform(-0.42, 0.42, 3) * room, rng.uniform(-3.2, 3.2, 3), s))
+    eye = off + rng.uniform(-0.3, 0.3, 3) * room
+    view = rng.normal(size=3)
+    view /= np.linalg.norm(view)
+    up = np.cross(view, rng.normal(size=3))
+    up /= np.linalg.norm(up)
+    return geoms, mats, eye, view, up, float(rng.uniform(15, 40))
+
+
+@pytest.mark.parametrize("seed", range(2))
+@pytest.mark.parametrize("kind", ["far", "huge", "tiny", "needle", "zero", "neg"])
+def test_extreme_scenes_bit_exact(pkg, kind, seed):
+    """The edges of fp32 (see _extreme_scene) on the per-primitive loop, the pair queue and the batched walk, resident paths on."""
+    geoms, mats, eye, view, up, fovy = _extreme_scene(kind, 100 + seed)
+    W, H, depth, iters = 64, 40, 8, 2
+    ga = (O.StaticGeom * len(geoms))(*geoms)
+    ma = (O.Material * len(mats))(*mats)
+    cam = O.make_camera(W, H, eye, view, up, fovy)
+    ref, live = O.render(ga, len(geoms), ma, len(mats), cam, depth, iters=iters, rr_start=-1, seed=seed)
+    for geom_path in (1, 3, 5, 7):
+        with pkg.Renderer(0) as r:
+            r.set_options(depth=depth, seed=seed, geom_path=geom_path, batch=2, resident=1)
+            r.set_scene(C.cast(ga, C.POINTER(pkg.StaticGeom)), len(geoms), C.cast(ma, C.POINTER(pkg.Material)), len(mats))
+            r.set_camera(pkg.CameraData.from_buffer_copy(cam))
+            r.clear_image()
+            r.render(1, iters)
+            img = r.download_image()
+            st = r.stats()
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (kind, seed, geom_path)
+        assert [int(x) for x in st.live_in[:depth]] == [int(x) for x in live], (kind, seed, geom_path)
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_resident_paths_self_skip_stress(pkg, seed):
     """A resident path that leaves a convex primitive on its outside skips that primitive at its next bounce -- only where the
