@@ -517,10 +517,23 @@ int configure(pt_ctx *c)
         o12[6] = e2.x; o12[7] = e2.y; o12[8] = e2.z;
         o12[9] = n.x; o12[10] = n.y; o12[11] = n.z;
     }
-    // padded world box of triangle t (culling only), same padding rule as prim_bounds
+    // centre and radius of a sphere around every point a ray can start from (set by the reach computation below) and, from them, how
+    // far from triangle t a ray tested against it can start
+    double scene_c0[3] = {0, 0, 0}, scene_rs = 0.0;
+    bool scene_known = false;
+    auto tri_reach = [&](size_t t) -> double {
+        if (!scene_known) return 0.0;
+        const float *w = &triw[12 * t];
+        const double cx = w[0] + ((double)w[3] + w[6]) / 3.0, cy = w[1] + ((double)w[4] + w[7]) / 3.0, cz = w[2] + ((double)w[5] + w[8]) / 3.0;
+        const double dx = cx - scene_c0[0], dy = cy - scene_c0[1], dz = cz - scene_c0[2];
+        return (sqrt(dx * dx + dy * dy + dz * dz) + scene_rs) * 1.002;
+    };
+    // padded world box of triangle t (culling only), same padding rule as prim_bounds: + 2e-6 x reach for what the reference's test and
+    // the kernels' slab tests lose on a ray that starts that far away (a unit triangle seen from 1e6 units is fuzzy by ~ 0.1)
     auto tri_bounds = [&](size_t t, double rel, double abs_pad) {
         const float *w = &triw[12 * t];
         Aabb b;
+        abs_pad += 2e-6 * tri_reach(t);
         for (int a = 0; a < 3; ++a) {
             const double p0 = w[a], p1 = (double)w[a] + w[3 + a], p2 = (double)w[a] + w[6 + a];
             const double lo = std::min(p0, std::min(p1, p2)), hi = std::max(p0, std::max(p1, p2));
@@ -567,6 +580,8 @@ int configure(pt_ctx *c)
             for (size_t t = 0; t < nT; ++t) grow_box(tri_bounds(t, 1.01, 1e-3));
             const double c0[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
             const double rs = 0.5 * sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+            scene_c0[0] = c0[0]; scene_c0[1] = c0[1]; scene_c0[2] = c0[2];
+            scene_rs = rs * 1.002;             // (the triangles' own pads, 2e-6 of it, are inside the 0.2 %)
             settled = true;
             for (size_t i = 0; i < nGeoms; ++i) {
                 auto dist = [&](const pt_static_geom &g) {
@@ -579,7 +594,8 @@ int configure(pt_ctx *c)
                 if (!(d <= reach[i])) { settled = false; reach[i] = d * 1.002; }          // (a NaN never settles)
             }
         }
-        if (!settled) for (size_t i = 0; i < nGeoms; ++i) reach[i] = 1e9;
+        if (!settled) { for (size_t i = 0; i < nGeoms; ++i) reach[i] = 1e9; scene_rs = 1e9; }
+        scene_known = true;
     }
     k.nG = (int)nP;
     k.ntri = (int)nT;
@@ -679,7 +695,7 @@ int configure(pt_ctx *c)
                              pz = w[2] + (j == 1 ? w[5] : (j == 2 ? w[8] : 0.0)) - cz;
                 r2 = std::max(r2, px * px + py * py + pz * pz);
             }
-            const double rad = sqrt(r2) * 1.02 + 1e-3;
+            const double rad = sqrt(r2) * 1.02 + 1e-3 + 2e-6 * tri_reach(t) + 4e-6 * (fabs(cx) + fabs(cy) + fabs(cz));
             p.cx = (float)cx; p.cy = (float)cy; p.cz = (float)cz;
             p.bound_r2 = (float)(rad * rad);
         }

@@ -49,13 +49,16 @@ def main():
         rng4 = np.random.default_rng(770000 + case)
         gopts["resident"] = int(rng4.choice([-1, 1, 1]))
         os.environ["PT_REFILL_MIN"] = str(int(rng4.choice([1, 4, 16, 33, 64])))
-        if rng4.random() < 0.2:
+        # (PT_FUZZ_SCENES=stress | extreme: every case from that generator -- for a targeted run)
+        p_stress = {"stress": 1.0, "extreme": 0.0}.get(os.environ.get("PT_FUZZ_SCENES", ""), 0.2)
+        p_extreme = {"stress": 0.0, "extreme": 1.0}.get(os.environ.get("PT_FUZZ_SCENES", ""), 0.1)
+        if rng4.random() < p_stress:
             # ... and scenes where the reference's sphere arithmetic loses its digits (spheres far smaller than the rays that reach them
             # are long: the culling bounds have to hold what the test HITS, and a resident path may only skip the primitive it leaves
             # where the test would miss it -- Prim::self_r2)
             geoms, mats, eye, view, up, fovy = _skip_stress_scene(5000 + case)
             n_prims = len(geoms)
-        elif rng4.random() < 0.1:
+        elif rng4.random() < p_extreme:
             # ... and scenes at the edges of fp32 (far from the origin, huge, tiny, needles, zero and negative scales)
             geoms, mats, eye, view, up, fovy = _extreme_scene(("far", "huge", "tiny", "needle", "zero", "neg")[case % 6], 5000 + case)
             n_prims = len(geoms)
@@ -108,6 +111,13 @@ def main():
             motion = (gba, cam_b, int(rng.integers(1, 6)))
             gopts["geom_path"] = int(rng.choice([0, 1, 5])) if n_prims <= 100 else int(rng.choice([0, 1]))
             strip = None if rng.random() < 0.5 else strip
+        if os.environ.get("PT_FUZZ_DUMP"):
+            # the case as data (for a look at it with the oracle alone): geoms, materials, camera as bytes, the options
+            import pickle
+            with open(os.environ["PT_FUZZ_DUMP"], "wb") as f:
+                pickle.dump(dict(case=case, geoms=bytes(ga), n_geoms=len(geoms), mats=bytes(ma), n_mats=len(mats), cam=bytes(cam), W=W, H=H,
+                                 depth=depth, iters=iters, opts=opts, gopts=gopts, strip=strip, meshes=meshes, motion=bool(motion)), f)
+            return 0
         sh = []
         if motion:
             kg, kc = O.motion_knots(ga, motion[0], len(geoms), cam, motion[1], motion[2])

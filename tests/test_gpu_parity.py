@@ -1374,6 +1374,17 @@ def test_fuzz_sample(pkg):
         sys.argv = old
 
 
+@pytest.mark.parametrize("case", [3514219, 3505609, 3403963, 3103489])
+def test_fuzz_cases_that_found_something(pkg, case, monkeypatch):
+    """Cases of tests/fuzz_gpu.py that exposed a defect, kept as they are.  3514219 / 3505609 / 3403963 (round 4): a mesh light two units
+    across in a scene 1.2e6 units wide -- the culling bounds of TRIANGLES had no pad for what a test loses on a ray that starts a million
+    units away, a shadow ray lost its occluder; 3103489: the camera span table against the fp32 ray grid of a huge scene (the image was
+    right, the bounds-checking build flagged the table)."""
+    import fuzz_gpu
+    monkeypatch.setattr(sys, "argv", ["fuzz_gpu.py", "1", str(case)])
+    assert fuzz_gpu.main() == 0
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # resident paths (pt_options.resident, round 4): the later bounces of a batch in ONE launch, paths kept in registers
 # ---------------------------------------------------------------------------------------------------------------
