@@ -148,7 +148,6 @@ typedef struct pt_options {
  *   PT_RESIDENT=1|0, PT_SEQUENCES=n     the library's choice where pt_options.resident / .sequences leave it open (== 0) -- an
  *                                       explicit option always wins
  *   PT_REFILL_MIN=n                     resident paths: free lanes that trigger a wave's refill (1..64, default 8)
- *   PT_CARRY_MAX=n                      resident pair kernel: leftover pairs of a trip that may wait for the next trip's batch (0..48, default 8)
  *   PT_NO_SELF_SKIP, PT_NO_SLAB         ablations of the pair reductions of DESIGN.md 5.1 (a resident path skipping the primitive it just
  *                                       left; tilted cubes clipped against the slab of their thinnest axis)
  *   PT_MAX_WG_PER_CU, PT_EXTRA_LDS, PT_NO_CULL, PT_NO_EYE_CULL     launch-shape / culling ablations behind DESIGN.md's sweeps

@@ -15,7 +15,8 @@ FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-
 GEOM = ["scalar", "LDS", "hit queue", "per-lane walk", "pair queue", "walk + pairs", "batched walk", "batched walk, nodes in L1/L2"]
 FEAT = {0: "plain", 1: "direct lighting", 2: "scattering", 3: "direct lighting + scattering", 4: "per-ray shutter time",
         5: "shutter time + direct lighting", 6: "shutter time + scattering", 7: "shutter time + both",
-        8: "resident paths", 9: "resident + direct lighting", 10: "resident + scattering", 11: "resident + both"}
+        8: "resident paths", 9: "resident + direct lighting", 10: "resident + scattering", 11: "resident + both",
+        16: "plain, slab pre-test", 24: "resident paths, slab pre-test"}
 
 
 def one(g):

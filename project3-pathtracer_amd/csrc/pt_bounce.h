@@ -538,18 +538,7 @@ struct PairQueue {
     f3 po, pd;                    // org == nullptr (batched walk): the calling lane's OWN ray; a pair's lane fetches its owner's
                                   // through ds_bpermute instead of from an LDS copy (1.5 KB per wave less)
     uint2 *mt;                    // [64] per owner lane (FEAT_MOTION only): the ray's shutter segment and fraction (MotionTime)
-    uint32_t *wait;               // [64] per owner lane (resident pair kernels only, same LDS as mt): scratch of the carry-over below
     unsigned long long *dbg;
-};
-// Resident pair kernels: what a wave's pair queues keep from one trip of its loop to the next.  A trip of the bundled scene queues
-// about as many pairs as a batch has lanes (~ 67 for ~ 60 rays): one batch is full, a second one would run the whole exact test for a
-// handful of lanes.  Those few pairs stay queued instead (`carry_max` of them at most), their owners sit the trip's shading out --
-// paths are independent, a lane simply keeps its path one trip longer -- and the next trip's first batch takes them along.  A pair
-// waits one trip at most: whatever was carried is tested before the next trip ends.
-// (Only box pairs are carried -- the mixed batch takes every sphere pair -- so the state is one word and a lane mask.)
-struct PairCarry {
-    uint32_t st = 0u;                                     // wave-uniform: where the box queue's carried pairs start (bits 0..7) | how many (bits 8..)
-    uint64_t wait = 0ull;                                 // lanes whose path waits for carried pairs
 };
 static constexpr uint32_t PAIR_QUEUE_BYTES = 2 * QCAP * 4 + 64 * 8 + 2 * 64 * 16 + 64 * 8;
 // LDS bytes per primitive of the pre-test's box table: eight (near, far) entries, one per direction octant
@@ -644,25 +633,19 @@ __device__ __forceinline__ void pairBatch(const KParams &p, const PR *s_prims, c
 // primitives the host marks: Prim::self_r2, pt_context.hip) -- but its origin lies inside the primitive's padded box, so the pre-test
 // would queue the pair every time: on the bundled scene, whose walls are tilted (ROTAT in radians) and fill the room with their
 // boxes, HALF of all pairs were such self pairs.  The bounds-checking build runs the exact test on every skipped pair and reports a hit.
-template <bool FIRST, class PR, bool MOTION = false, bool SKIP = false, bool CARRY = false>
+template <bool FIRST, class PR, bool MOTION = false, bool SKIP = false, bool SLAB = false>
 __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_prims, const float4 *s_boxes, const PairQueue q,
                                                f3 o, f3 d, bool valid, uint32_t lane, uint32_t primmask, MotionTime mymt = MotionTime(),
-                                               uint32_t skip = 0xFFFFFFFFu, PairCarry *pc = nullptr)
+                                               uint32_t skip = 0xFFFFFFFFu)
 {
     const unsigned long long ph_in = LANE_BUDGET<FIRST>() ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long fb_clk = 0ull, lb_lane_clk = 0ull;      // DEBUG_PHASE2: clocks inside full batches; lane-clocks of the last batches
-    // CARRY: lanes whose path waits for pairs carried over from the last trip keep their key, ray and queue entries
-    const bool fresh = CARRY ? !__builtin_amdgcn_inverse_ballot_w64(pc->wait) : true;
-    if (fresh) {
-        q.key[lane] = KEY_NONE;
-        q.org[lane] = make_float4(o.x, o.y, o.z, d.x);
-        q.dir[lane] = make_float2(d.y, d.z);
-    }
+    q.key[lane] = KEY_NONE;
+    q.org[lane] = make_float4(o.x, o.y, o.z, d.x);
+    q.dir[lane] = make_float2(d.y, d.z);
     if (MOTION) q.mt[lane] = make_uint2(mymt.k, __float_as_uint(mymt.f));
     uint32_t head[2] = {0u, 0u}, tail[2] = {0u, 0u};        // wave-uniform
-    if (CARRY) { head[1] = pc->st & 0xFFu; tail[1] = head[1] + (pc->st >> 8); }
-    const uint32_t old_end0 = 0u, old_end1 = tail[1];        // CARRY: the carried pairs end here
-    const uint64_t vmask = CARRY ? (__ballot(valid) & ~pc->wait) : __ballot(valid);
+    const uint64_t vmask = __ballot(valid);
     const f3 dinv = approxInverse(d);
     // slab distances as fma(plane, 1/d, -o/d): one instruction per plane; against (plane - o)/d this moves a plane by
     // less than 1.2e-6 |o|, far inside the boxes' padding
@@ -695,7 +678,7 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
         static_assert(sizeof(PR) == 144, "the slab sits in the pad of the records' LDS copies");
         // a tilted cube fills little of its world box: the ray is also clipped against the slab between the two faces of the cube's thinnest
         // axis (host: KParams::slab_mask; planes n.x = d_lo / d_hi, n and d_lo in the pad of the record's LDS copy, d_hi in the far entry's w)
-        if (!MOTION && (uint32_t)g < 32u && ((p.slab_mask >> (uint32_t)g) & 1u) != 0u) {              // wave-uniform
+        if (SLAB && (uint32_t)g < 32u && ((p.slab_mask >> (uint32_t)g) & 1u) != 0u) {                 // wave-uniform
             const float4 s4 = reinterpret_cast<const float4 *>(&s_prims[g])[8];
             const float nd = __builtin_fmaf(s4.z, d.z, __builtin_fmaf(s4.y, d.y, s4.x * d.x));
             const float no = __builtin_fmaf(s4.z, o.z, __builtin_fmaf(s4.y, o.y, s4.x * o.x));
@@ -706,7 +689,7 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
         }
         // the compare's lane mask straight from v_cmp, and back into a predicate without VALU work
         uint64_t mask = __builtin_amdgcn_fcmpf(tnn, tf, FCMP_OLE) & vmask;
-        if (DEBUG_BOUNDS && !MOTION) {
+        if (DEBUG_BOUNDS && SLAB) {
             // (bounds-checking build: the exact test of every pair the slab turned away; a hit is reported)
             const uint64_t turned = (__builtin_amdgcn_fcmpf(tn, tf_box, FCMP_OLE) & vmask) & ~mask;
             if (turned != 0ull) {
@@ -747,37 +730,17 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
             }
         }
     }
+    const uint64_t dbg_valid = DEBUG_PAIR ? __ballot(valid) : 0ull;
     if (DEBUG_PAIR && lane == 0) {
-        atomicAdd(&p.st->dbg[0], (unsigned long long)(tail[0] - old_end0));
-        atomicAdd(&p.st->dbg[1], (unsigned long long)(tail[1] - old_end1));
-        atomicAdd(&p.st->dbg[4], (unsigned long long)__popcll(vmask));
-        atomicAdd(&p.st->dbg[5], (unsigned long long)((tail[0] - old_end0 + 63) / 64 + (tail[1] - old_end1 + 63) / 64));
+        atomicAdd(&p.st->dbg[0], (unsigned long long)tail[0]);
+        atomicAdd(&p.st->dbg[1], (unsigned long long)tail[1]);
+        atomicAdd(&p.st->dbg[4], (unsigned long long)__popcll(dbg_valid));
+        atomicAdd(&p.st->dbg[5], (unsigned long long)((tail[0] + 63) / 64 + (tail[1] + 63) / 64));
         atomicAdd(&p.st->dbg[6], 1ull);
     }
     const unsigned long long ph_a = LANE_BUDGET<FIRST>() ? __builtin_amdgcn_s_memtime() : 0ull;
     const uint32_t left0 = tail[0] - head[0], left1 = tail[1] - head[1];      // both < 64
-    uint64_t waitnow = 0ull;                                                   // CARRY: lanes whose pairs stay queued
-    bool handled = false;
-    if (CARRY && p.carry_max > 0) {
-        // carried pairs not yet taken by a full batch of this trip: they must go now
-        const uint32_t old1 = (int32_t)(old_end1 - head[1]) > 0 ? old_end1 - head[1] : 0u;
-        const uint32_t total = left0 + left1;
-        if (total > 64u && total - 64u <= (uint32_t)p.carry_max && old1 <= 64u - left0) {
-            // one full mixed batch -- every sphere pair, box pairs up to 64 lanes -- and the few box pairs beyond it wait
-            pairBatch<2u, FIRST, PR, MOTION>(p, s_prims, q, head[0], left0, lane, head[1], 64u - left0);
-            head[0] += left0; head[1] += 64u - left0;
-            const uint32_t c1 = total - 64u;
-            handled = true;
-            // their owners: flags in LDS, set by the lanes that read the carried entries
-            q.wait[lane] = 0u;
-            wave_lds_fence();
-            if (lane < c1) q.wait[q.q[1][(head[1] + lane) & (QCAP - 1u)] & 63u] = 1u;
-            wave_lds_fence();
-            waitnow = __ballot(q.wait[lane] != 0u);
-        }
-    }
-    if (handled) {
-    } else if (left0 != 0u && left1 != 0u && left0 + left1 <= 64u) {
+    if (left0 != 0u && left1 != 0u && left0 + left1 <= 64u) {
         pairBatch<2u, FIRST, PR, MOTION>(p, s_prims, q, head[0], left0, lane, head[1], left1);   // one mixed batch instead of two partial ones
         if (LANE_BUDGET<FIRST>()) lb_lane_clk += (__builtin_amdgcn_s_memtime() - ph_a) * (unsigned long long)(left0 + left1);
     } else {
@@ -786,12 +749,6 @@ __device__ __forceinline__ Hit nearestHitPairs(const KParams &p, const PR *s_pri
         if (LANE_BUDGET<FIRST>()) lb_lane_clk += (ph_b - ph_a) * (unsigned long long)left0;
         if (left1 != 0u) pairBatch<1u, FIRST, PR, MOTION>(p, s_prims, q, head[1], left1, lane);
         if (LANE_BUDGET<FIRST>()) lb_lane_clk += (__builtin_amdgcn_s_memtime() - ph_b) * (unsigned long long)left1;
-    }
-    if (CARRY) {
-        if (!handled) head[1] = tail[1];
-        pc->st = (head[1] & (QCAP - 1u)) | ((tail[1] - head[1]) << 8);
-        pc->wait = waitnow;
-        if (__builtin_amdgcn_inverse_ballot_w64(waitnow)) valid = false;       // (no result yet for a path that waits)
     }
     wave_lds_fence();
     Hit h;
@@ -1256,10 +1213,10 @@ __device__ __forceinline__ Hit nearestHitWalk4(const KParams &p, const Prim *pri
 
 // nearest hit of (o, d) for the lanes with want == true, by the GEOM path.  Every lane of the wave must make the call
 // (the hit queue uses all 64 lanes as workers whatever their own ray).
-template <int GEOM, bool FIRST, bool MOTION = false, bool SKIP = false, bool CARRY = false>
+template <int GEOM, bool FIRST, bool MOTION = false, bool SKIP = false, bool SLAB = false>
 __device__ __forceinline__ Hit nearestHit(const KParams &p, const PrimPad *s_prims, const float4 *s_nodes, const WaveQueue &wq,
                                           f3 o, f3 d, bool want, uint32_t lane, uint32_t primmask = 0xFFFFFFFFu, MotionTime mt = MotionTime(),
-                                          uint32_t skip = 0xFFFFFFFFu, PairCarry *pc = nullptr)
+                                          uint32_t skip = 0xFFFFFFFFu)
 {
     if (GEOM == GEOM_QUEUE) return nearestHitQueued<FIRST>(p, s_prims, wq, o, d, want, lane);
     if (GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR || GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) {
@@ -1272,7 +1229,6 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const PrimPad *s_pri
         pq.org = reinterpret_cast<float4 *>(b + 2 * QCAP * 4 + 64 * 8 + 64 * 16);
         pq.dir = reinterpret_cast<float2 *>(b + 2 * QCAP * 4 + 64 * 8 + 2 * 64 * 16);
         pq.mt = reinterpret_cast<uint2 *>(b + PAIR_QUEUE_BYTES);           // (carved for FEAT_MOTION instances only)
-        pq.wait = reinterpret_cast<uint32_t *>(b + PAIR_QUEUE_BYTES);      // (... and for the resident pair kernels)
         pq.dbg = p.st->dbg;
         pq.tq = nullptr;
         if (GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) {
@@ -1287,7 +1243,7 @@ __device__ __forceinline__ Hit nearestHit(const KParams &p, const PrimPad *s_pri
             return nearestHitWalk4<FIRST, SKIP>(p, p.prims, w4, pq, o, d, want, lane, (FIRST && p.span_off != nullptr) ? primmask : 0xFFFFFFFFu, skip);
         }
         if (GEOM == GEOM_WALK_PAIR) return nearestHitWalkPairs<FIRST>(p, p.prims, s_nodes, pq, o, d, want, lane);
-        return nearestHitPairs<FIRST, PrimPad, MOTION, SKIP, CARRY && GEOM == GEOM_PAIR>(p, s_prims, s_nodes, pq, o, d, want, lane, primmask, mt, skip, pc);
+        return nearestHitPairs<FIRST, PrimPad, MOTION, SKIP, SLAB && GEOM == GEOM_PAIR>(p, s_prims, s_nodes, pq, o, d, want, lane, primmask, mt, skip);
     }
     Hit h;
     h.any = false;
@@ -1334,15 +1290,16 @@ __device__ __forceinline__ uint32_t globalPixel(const KParams &p, uint32_t pl)
 //         traces a path: every RNG stream is keyed on (global pixel, iteration, bounce) -- the stream keys of all bounces sit in an
 //         LDS table --, a path still writes its one radiance sample when it ends, and the per-bounce live counts come from an
 //         LDS histogram of the bounce each path ended at.
-enum { FEAT_NEE = 1, FEAT_MEDIA = 2, FEAT_MOTION = 4, FEAT_RESIDENT = 8 };
+enum { FEAT_NEE = 1, FEAT_MEDIA = 2, FEAT_MOTION = 4, FEAT_RESIDENT = 8, FEAT_SLAB = 16 };
 template <int WG, bool FIRST, int GEOM, int COMPACT, int FEAT = 0>
 // (the resident-path instances of the batched walks are held to 80 VGPRs -- 6 waves per SIMD, three 512-thread workgroups per CU,
 // what the launch-per-bounce kernels reach unasked)
-__global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G)) ? 6
-                                 : ((WG <= 256 && (FEAT & ~FEAT_RESIDENT) == 0) ? 5 : 1)) void k_bounce(const KParams p, const int bounce)
+__global__ __launch_bounds__(WG, ((FEAT & ~FEAT_SLAB) == FEAT_RESIDENT && (GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G)) ? 6
+                                 : ((WG <= 256 && (FEAT & ~(FEAT_RESIDENT | FEAT_SLAB)) == 0) ? 5 : 1)) void k_bounce(const KParams p, const int bounce)
 {
     constexpr bool NEE = (FEAT & FEAT_NEE) != 0, MEDIA = (FEAT & FEAT_MEDIA) != 0, MOTION = (FEAT & FEAT_MOTION) != 0;
     constexpr bool RESIDENT = (FEAT & FEAT_RESIDENT) != 0;
+    constexpr bool SLAB = (FEAT & FEAT_SLAB) != 0;       // pair path: the pre-test also clips tilted cubes against the slab of their thinnest axis (plain kernels only)
     static_assert(!RESIDENT || (!FIRST && COMPACT == 1 && !MOTION), "resident paths: later bounces, compaction 1, no per-ray shutter time");
     constexpr int NW = WG / 64;
     constexpr bool PRIMS_IN_LDS = (GEOM == GEOM_LDS || GEOM == GEOM_QUEUE || GEOM == GEOM_PAIR);   // GEOM_BVH gathers records from global memory (L1/L2)
@@ -1357,7 +1314,7 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
                                                  : (GEOM == GEOM_PAIR ? p.nG * PAIR_BOX_BYTES * (NEE ? 2 : 1) : 0));
     unsigned char *s_queue = smem + prim_bytes + node_bytes;
     const int WAVE_LDS = (GEOM == GEOM_QUEUE) ? (int)WAVE_QUEUE_BYTES
-                         : ((GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR) ? (int)(((MOTION || RESIDENT) && GEOM == GEOM_PAIR) ? PAIR_QUEUE_MOTION_BYTES : PAIR_QUEUE_BYTES)
+                         : ((GEOM == GEOM_PAIR || GEOM == GEOM_WALK_PAIR) ? (int)((MOTION && GEOM == GEOM_PAIR) ? PAIR_QUEUE_MOTION_BYTES : PAIR_QUEUE_BYTES)
                             : ((GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) ? (int)walk4_wave_bytes(p.ntri) : 0));
     const int queue_bytes = NW * WAVE_LDS;
     float *s_mats = reinterpret_cast<float *>(s_queue + queue_bytes);
@@ -1384,7 +1341,7 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
         const uint4 *src = reinterpret_cast<const uint4 *>(p.prims);
         uint4 *dst = reinterpret_cast<uint4 *>(s_prims);
         for (int k = tid; k < p.nG * 8; k += WG) dst[(k >> 3) * 9 + (k & 7)] = src[k];
-        if (GEOM == GEOM_PAIR)                                // ... and in the pad the pre-test's slab (n.xyz, d_lo)
+        if (SLAB)                                             // ... and in the pad the pre-test's slab (n.xyz, d_lo)
             for (int k = tid; k < p.nG; k += WG) dst[k * 9 + 8] = reinterpret_cast<const uint4 *>(p.slab_n)[k];
         const uint4 *fsrc = reinterpret_cast<const uint4 *>(p.face_n);
         for (int k = tid; k < p.nG * 8; k += WG) dst[p.nG * 9 + (k >> 3) * 9 + (k & 7)] = fsrc[k];
@@ -1558,9 +1515,6 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
             wflags = (wflags & ~WF_SHARD) | ((rot + (uint32_t)__builtin_ctz(m)) & WF_SHARD);
         }
     };
-    // resident pair kernels without shadow rays (those share the queues): leftover pairs of a trip may wait for the next one's batch
-    constexpr bool CARRY = RESIDENT && GEOM == GEOM_PAIR && !NEE && !MEDIA;
-    PairCarry carry;
     // RESIDENT: the path a lane carries from one trip of the loop to the next (else: this trip's ray)
     bool valid = false;
     f3 o = mk(0, 0, 0), d = mk(0, 0, 0), T = mk(1, 1, 1);
@@ -1743,13 +1697,10 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
             h.any = false; h.material = 0; h.prim = 0; h.t = 0.0f; h.p = mk(0, 0, 0); h.n = mk(0, 0, 0);
             if (valid) h = nearestHitMotion(p, o, d, mt);
         } else {
-            if (RESIDENT) h = nearestHit<GEOM, false, false, true, CARRY>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane, 0xFFFFFFFFu, MotionTime(), (lb >> 8) - 1u, &carry);
-            else h = (FIRST && p.lens_radius > 0.0f) ? nearestHit<GEOM, false>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane)
-                                                     : nearestHit<GEOM, FIRST>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane, primmask);
+            if (RESIDENT) h = nearestHit<GEOM, false, false, true, SLAB>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane, 0xFFFFFFFFu, MotionTime(), (lb >> 8) - 1u);
+            else h = (FIRST && p.lens_radius > 0.0f) ? nearestHit<GEOM, false, false, false, SLAB>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane)
+                                                     : nearestHit<GEOM, FIRST, false, false, SLAB>(p, s_prims, s_nodes, wq, o, d, valid, (uint32_t)lane, primmask);
         }
-        // CARRY: a path whose last pairs stay queued for the next trip's batch sits this trip's shading out
-        const bool held = CARRY ? (valid && __builtin_amdgcn_inverse_ballot_w64(carry.wait)) : false;
-        if (CARRY) valid = valid && !held;
         const unsigned long long c2 = (DEBUG_PHASE || PT_DEBUG_PHASE == 2 || PT_DEBUG_PHASE == 3) ? __builtin_amdgcn_s_memtime() : 0ull;
         if (LANE_BUDGET<FIRST>()) { lb_nvalid = (uint32_t)__popcll(__ballot(valid)); lb_nhit = (uint32_t)__popcll(__ballot(valid && h.any)); }
         bool did_bsdf = false;            // (DEBUG_PHASE2)
@@ -2029,8 +1980,8 @@ __global__ __launch_bounds__(WG, (FEAT == FEAT_RESIDENT && (GEOM == GEOM_WALK4 |
             // a path that ended is counted at the bounce it ended at (the per-bounce live counts follow from the histogram);
             // one that goes on stays where it is, a bounce further
             if (valid && !alive) atomicAdd(&s_term[cb], 1u);
-            valid = alive || held;
-            if (!held) lb = (cb + 1u) | (leaves_outside ? ((h.prim + 1u) << 8) : 0u);
+            valid = alive;
+            lb = (cb + 1u) | (leaves_outside ? ((h.prim + 1u) << 8) : 0u);
             if (DEBUG_PHASE2 && GEOM == GEOM_PAIR) { const unsigned long long c4 = __builtin_amdgcn_s_memtime() - c3; lbud[11] += c4; lbud[12] += c4 * (unsigned long long)__popcll(__ballot(alive)); }
             continue;
         }
@@ -2162,6 +2113,8 @@ static const void *bounce_fn_geom(bool first, int compact, int feat)
         if constexpr ((GEOM == GEOM_PAIR || GEOM == GEOM_WALK4 || GEOM == GEOM_WALK4G) && (WG == 256 || WG == 512)) {
             if (compact != 1 || first) return nullptr;
             if (feat == FEAT_RESIDENT) return (const void *)k_bounce<WG, false, GEOM, 1, FEAT_RESIDENT>;
+            if constexpr (GEOM == GEOM_PAIR)
+                if (feat == (FEAT_RESIDENT | FEAT_SLAB)) return (const void *)k_bounce<WG, false, GEOM, 1, FEAT_RESIDENT | FEAT_SLAB>;
             if (feat == (FEAT_RESIDENT | FEAT_NEE)) return (const void *)k_bounce<WG, false, GEOM, 1, FEAT_RESIDENT | FEAT_NEE>;
             if (feat == (FEAT_RESIDENT | FEAT_MEDIA)) return (const void *)k_bounce<WG, false, GEOM, 1, FEAT_RESIDENT | FEAT_MEDIA>;
             if (feat == (FEAT_RESIDENT | FEAT_NEE | FEAT_MEDIA)) return (const void *)k_bounce<WG, false, GEOM, 1, FEAT_RESIDENT | FEAT_NEE | FEAT_MEDIA>;
@@ -2170,6 +2123,12 @@ static const void *bounce_fn_geom(bool first, int compact, int feat)
     }
     if (feat != 0) {
         if (compact != 1) return nullptr;
+        if ((feat & FEAT_SLAB) != 0) {        // the pre-test with slabs: plain pair-queue kernels, workgroups of 256 / 512
+            if constexpr (GEOM == GEOM_PAIR && (WG == 256 || WG == 512)) {
+                if (feat == FEAT_SLAB) return bounce_fn_feat<WG, GEOM, FEAT_SLAB>(first);
+            }
+            return nullptr;
+        }
         if ((feat & FEAT_MOTION) != 0) {      // per-ray shutter time: the scalar and the pair path, 256-thread workgroups only
             if constexpr ((GEOM == GEOM_SCALAR || GEOM == GEOM_PAIR) && WG == 256) {
                 if (feat == FEAT_MOTION) return bounce_fn_feat<256, GEOM, FEAT_MOTION>(first);

@@ -21,9 +21,6 @@
 #ifndef PT_RESIDENT_DEFAULT
 #define PT_RESIDENT_DEFAULT 1
 #endif
-#ifndef PT_CARRY_MAX_DEFAULT
-#define PT_CARRY_MAX_DEFAULT 8
-#endif
 #ifndef PT_REFILL_MIN_DEFAULT
 #define PT_REFILL_MIN_DEFAULT 8
 #endif
@@ -596,6 +593,7 @@ int configure(pt_ctx *c)
         }
         if (!settled) { for (size_t i = 0; i < nGeoms; ++i) reach[i] = 1e9; scene_rs = 1e9; }
         scene_known = true;
+        if (getenv("PT_NO_NOISE_PAD")) { for (size_t i = 0; i < nGeoms; ++i) reach[i] = 0.0; scene_known = false; }      // (ablation: rounds 1-3's bounds)
     }
     k.nG = (int)nP;
     k.ntri = (int)nT;
@@ -1100,6 +1098,13 @@ int configure(pt_ctx *c)
         return fail(PT_ERR_INVALID, "scatter needs workgroup 0, 256 or 512 (got %d)", cfg.workgroup);
     k.cull = (k.nG > 32 && !getenv("PT_NO_CULL")) ? 1 : 0;
     k.nshard = (cfg.compact == 1) ? pt::NSHARD : 1;
+    // the pre-test with slabs (pair path): kernel instances of their own, taken only where a cube of the scene has a slab (decided again at
+    // the end, should a fallback below change the launch shape)
+    auto slab_wanted = [&]() {
+        return (k.slab_mask != 0u && cfg.geom == 4 && cfg.compact == 1 && (cfg.workgroup == 256 || cfg.workgroup == 512) && !cfg.nee && !cfg.media &&
+                !cfg.motion) ? 1 : 0;
+    };
+    cfg.slab = slab_wanted();
     // resident paths (pt_options.resident): the camera launch as ever, then ONE launch that traces bounces 1 .. depth - 1 with the
     // paths kept in registers -- where a kernel instance exists (pair queue / batched walks, plain kernels) and there is more
     // than one later bounce to fuse; everything else keeps the launch per bounce
@@ -1122,9 +1127,6 @@ int configure(pt_ctx *c)
         k.refill_min = getenv("PT_REFILL_MIN") ? atoi(getenv("PT_REFILL_MIN")) : PT_REFILL_MIN_DEFAULT;
         if (k.refill_min < 1) k.refill_min = 1;
         if (k.refill_min > 64) k.refill_min = 64;
-        k.carry_max = getenv("PT_CARRY_MAX") ? atoi(getenv("PT_CARRY_MAX")) : PT_CARRY_MAX_DEFAULT;
-        if (k.carry_max < 0) k.carry_max = 0;
-        if (k.carry_max > 48) k.carry_max = 48;
     }
     size_t lds = pt::bounce_lds_bytes(k, cfg);
     if ((cfg.geom == 6 || cfg.geom == 7) && o.workgroup == 0) {
@@ -1184,6 +1186,8 @@ int configure(pt_ctx *c)
     if (grid < 1) grid = 1;
     cfg.grid = (int)grid;
     if (cfg.resident && !pt::bounce_resident_available(cfg)) cfg.resident = 0;      // (a fallback above changed the launch shape)
+    cfg.slab = slab_wanted();
+    if (!cfg.slab) k.slab_mask = 0u;
     if (getenv("PT_DEBUG_CLOCK"))
         fprintf(stderr, "[ptamd] launch: geom %d, workgroup %d, %zu B LDS, %d workgroups/CU, grid %d, batch %d, resident paths %d (refill at %d free lanes)\n", cfg.geom, cfg.workgroup,
                 lds, per_cu, cfg.grid, batch, cfg.resident, k.refill_min);

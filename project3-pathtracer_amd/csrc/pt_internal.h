@@ -124,7 +124,6 @@ struct KParams {
     int nknots;            // 0 = off
     float tan_x, tan_y;    // tan of the half field-of-view angles (the per-ray camera basis is built on the device)
     int refill_min;        // resident paths (FEAT_RESIDENT kernels): a wave refills its free lanes from the pool once this many are free
-    int carry_max;         // resident pair kernels: at most this many leftover pairs of a trip wait for the next trip's batch (0: none; PairCarry)
 };
 
 struct LaunchCfg {
@@ -138,6 +137,9 @@ struct LaunchCfg {
     int motion;      // 1 = per-ray shutter time (geom 0, workgroup 256, compact 1, neither nee nor media)
     int resident;    // 1 = bounces 1 .. depth - 1 in ONE launch, paths resident in registers (geom 4, 6, 7; workgroup 256 / 512; compact 1;
                      //     none of nee / media / motion)
+    int slab;        // 1 = the pair path's pre-test also clips tilted cubes against the slab of their thinnest axis (KParams::slab_mask != 0;
+                     //     geom 4, workgroup 256 / 512, compact 1, none of nee / media / motion): kernel instances of their own, so that scenes
+                     //     without such cubes keep the shorter loop
 };
 
 // kernels (pt_kernels.hip)

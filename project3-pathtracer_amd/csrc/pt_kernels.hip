@@ -260,7 +260,7 @@ size_t bounce_lds_bytes(const KParams &p, const LaunchCfg &cfg)
 {
     size_t prim = (cfg.geom == GEOM_LDS || cfg.geom == GEOM_QUEUE || cfg.geom == GEOM_PAIR) ? (size_t)p.nG * 2 * sizeof(PrimPad) : 0;
     size_t queue = (size_t)(cfg.workgroup / 64) * (cfg.geom == GEOM_QUEUE ? WAVE_QUEUE_BYTES
-                                                   : ((cfg.geom == GEOM_PAIR || cfg.geom == GEOM_WALK_PAIR) ? (((cfg.motion || cfg.resident) && cfg.geom == GEOM_PAIR) ? PAIR_QUEUE_MOTION_BYTES : PAIR_QUEUE_BYTES)
+                                                   : ((cfg.geom == GEOM_PAIR || cfg.geom == GEOM_WALK_PAIR) ? ((cfg.motion && cfg.geom == GEOM_PAIR) ? PAIR_QUEUE_MOTION_BYTES : PAIR_QUEUE_BYTES)
                                                       : ((cfg.geom == GEOM_WALK4 || cfg.geom == GEOM_WALK4G) ? walk4_wave_bytes(p.ntri) : 0)));
     if (cfg.geom == GEOM_WALK4) prim += ((size_t)p.nnodes4 * W4_FLOATS * 4 + 127) & ~(size_t)127;
     if (cfg.geom == GEOM_BVH || cfg.geom == GEOM_WALK_PAIR) prim += (size_t)p.nnodes * sizeof(BvhNode);
@@ -285,7 +285,7 @@ const void *bounce_kernel_g7(int workgroup, bool first, int compact, int feat);
 
 static const void *select_bounce(const LaunchCfg &cfg, bool first)
 {
-    const int feat = cfg.nee | (cfg.media << 1) | (cfg.motion << 2) | ((cfg.resident && !first) ? FEAT_RESIDENT : 0);
+    const int feat = cfg.nee | (cfg.media << 1) | (cfg.motion << 2) | ((cfg.resident && !first) ? FEAT_RESIDENT : 0) | (cfg.slab ? FEAT_SLAB : 0);
     switch (cfg.geom) {
     case GEOM_SCALAR: return bounce_kernel_g0(cfg.workgroup, first, cfg.compact, feat);
     case GEOM_LDS: return bounce_kernel_g1(cfg.workgroup, first, cfg.compact, feat);
