@@ -150,6 +150,8 @@ typedef struct pt_options {
  *   PT_REFILL_MIN=n                     resident paths: free lanes that trigger a wave's refill (1..64, default 8)
  *   PT_NO_SELF_SKIP, PT_NO_SLAB         ablations of the pair reductions of DESIGN.md 5.1 (a resident path skipping the primitive it just
  *                                       left; tilted cubes clipped against the slab of their thinnest axis)
+ *   PT_NO_NOISE_PAD                     ablation: culling bounds without the reach-based pads (rounds 1-3's bounds -- NOT conservative for
+ *                                       spheres far smaller than the rays that reach them are long, or scenes ~ 1e6 units wide: DESIGN.md 2)
  *   PT_MAX_WG_PER_CU, PT_EXTRA_LDS, PT_NO_CULL, PT_NO_EYE_CULL     launch-shape / culling ablations behind DESIGN.md's sweeps
  *   PT_DEBUG_CLOCK, PT_DEBUG_PHASE, PT_DEBUG_PHASE2, PT_DEBUG_PAIR, PT_DEBUG_W4, PT_DEBUG_SPAN, PT_DEBUG_BOUNDS
  *                                       print diagnostics at pt_get_stats (the counters exist in diagnostic builds only)
