@@ -455,7 +455,7 @@ def main():
                 "rotat_units": args.rotat, "primitives": sc.n_objects, "materials": sc.n_materials,
                 "compaction": 0 if args.no_compaction else args.compaction, "iteration_batch": lib_batch, "timed_batches": timed_batches,
                 "launch_sequences_in_flight": li.sequences, "geom_path": li.geom_path, "workgroup": li.workgroup, "grid": li.grid,
-                "resident_paths": bool(li.resident), "bounce_launches_per_batch": li.launches_per_batch, "lds_bytes_per_workgroup": li.lds_bytes,
+                "resident_paths": bool(li.resident), "slab_pretest": bool(li.slab_pretest), "bounce_launches_per_batch": li.launches_per_batch, "lds_bytes_per_workgroup": li.lds_bytes,
                 "hip_graph": not args.no_graph, "direct_light": bool(args.direct_light),
                 "parallelism": (f"pixel-strips x{world}" if strips else f"pixel-bands x{world}") +
                                (", 1 RCCL gather of the rendered frame behind the timed steps" if world > 1 else ""),

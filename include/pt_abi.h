@@ -258,7 +258,9 @@ typedef struct pt_launch_info {
     int refill_min;       /*   free lanes that trigger a wave's refill there */
     int launches_per_batch;   /* bounce-kernel launches per batch: depth, or 2 with resident paths */
     int lds_bytes;        /* dynamic LDS per workgroup of the later-bounce kernel */
-    int reserved[7];
+    int slab_pretest;     /* 1 = the pair queue's pre-test also clips tilted cubes against the slab of their thinnest axis (kernel instances of
+                             their own, taken where a cube of the scene has such a slab: DESIGN.md 5.1); was reserved[0], the size is unchanged */
+    int reserved[6];
 } pt_launch_info;
 int  pt_get_launch_info(pt_ctx *ctx, pt_launch_info *out);
 

@@ -79,7 +79,7 @@ class Stats(C.Structure):
 class LaunchInfo(C.Structure):      # pt_launch_info
     _fields_ = [("geom_path", C.c_int), ("workgroup", C.c_int), ("grid", C.c_int), ("batch", C.c_int), ("sequences", C.c_int),
                 ("resident", C.c_int), ("refill_min", C.c_int), ("launches_per_batch", C.c_int), ("lds_bytes", C.c_int),
-                ("reserved", C.c_int * 7)]
+                ("slab_pretest", C.c_int), ("reserved", C.c_int * 6)]
 
 
 class Mesh(C.Structure):            # pt_mesh: triangles of one MESH geom, object space, 9 floats each

@@ -2092,6 +2092,7 @@ int pt_get_launch_info(pt_ctx *c, pt_launch_info *out)
     out->refill_min = c->kp.refill_min;
     out->launches_per_batch = bounce_launches_per_batch(c);
     out->lds_bytes = (int)pt::bounce_lds_bytes(c->kp, c->cfg);
+    out->slab_pretest = c->cfg.slab;
     return PT_OK;
 }
 

@@ -1529,6 +1529,30 @@ def test_extreme_scenes_bit_exact(pkg, kind, seed):
         assert [int(x) for x in st.live_in[:depth]] == [int(x) for x in live], (kind, seed, geom_path)
 
 
+def test_slab_pretest_is_chosen_per_scene(pkg):
+    """The pre-test with slabs (FEAT_SLAB kernel instances) is taken where a cube of the scene is tilted enough to have one -- the bundled
+    scene with ROTAT read as radians -- and only by the plain pair-queue kernels; the image is the oracle's either way."""
+    def info(rotat, **opts):
+        sc = pkg.SceneFile(os.path.join(SCENES, "sampleScene_spec.txt"), rotat)
+        sc.set_resolution(64, 48)
+        with pkg.Renderer(0) as r:
+            r.set_options(depth=6, **opts)
+            r.set_scene(sc.geoms, sc.n_objects, sc.mats, sc.n_materials)
+            r.set_camera(sc.camera)
+            r.clear_image()
+            r.render(1, 1)
+            return r.launch_info()
+    assert info(0).slab_pretest == 1 and info(0).resident == 1
+    assert info(0, resident=-1).slab_pretest == 1                 # the launch-per-bounce kernels take it too
+    assert info(1).slab_pretest == 0                              # degrees: axis-aligned walls
+    assert info(0, direct_light=1).slab_pretest == 0              # shadow rays share the queues: plain kernels only
+    assert info(0, geom_path=7).slab_pretest == 0                 # the batched walk has no such loop
+    for rotat in (0, 1):
+        g, lg, _ = gpu_render(pkg, "sampleScene_spec.txt", 97, 61, 7, iters=3, rotat=rotat)
+        c, lc = cpu_render("sampleScene_spec.txt", 97, 61, 7, iters=3, rotat=rotat)
+        check(g, c, lg, lc, f"slab pre-test, rotat {rotat}")
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_resident_paths_self_skip_stress(pkg, seed):
     """A resident path that leaves a convex primitive on its outside skips that primitive at its next bounce -- only where the
